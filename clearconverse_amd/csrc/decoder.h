@@ -1,0 +1,56 @@
+// decoder.h -- parameter blocks and launchers for the decoder step kernels (decoder.hip).
+#pragma once
+#include "ccx_common.h"
+
+enum { ACT_LN = 0, ACT_BF16 = 1, ACT_COMBINE = 2 };
+enum { DEPI_BF16 = 0, DEPI_BF16_GELU = 1, DEPI_F32_ACCUM = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4 };
+
+struct DecLinearParams {
+  int M, N, K;
+  const bf16_t* W; long ldw;      // [N][K]
+  const float* bias;              // [N] or null
+  // activation sources
+  const float* x;                 // ACT_LN: [M][K] f32 residual stream
+  const float* ln_g; const float* ln_b; float eps;
+  const bf16_t* act; long lda;    // ACT_BF16: [M][K]
+  const float* part_o; const float* part_ml; int nsplit;  // ACT_COMBINE: [M][H][nsplit][64], [M][H][nsplit][2]
+  // outputs
+  void* out; long ldo;
+  // DEPI_SELF_QKV: q -> out (f32 [M][K]), k/v -> caches [M][H][cache_T][64] at pos[m]
+  bf16_t* cache_k; bf16_t* cache_v; int cache_T; const int* pos;
+};
+int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams& p, hipStream_t stream);
+
+struct DecAttnParams {
+  const float* q;       // [B][H][64] f32
+  const bf16_t* k;      // [B][H][kv_T][64]
+  const bf16_t* v;
+  int H, kv_T;
+  const int* pos;       // if non-null: keys = pos[b] + 1 (self attention), else T
+  int T;
+  float scale_log2e;
+  bf16_t* out_bf16;     // FINAL: [B][H*64]
+  float* part_o;        // partials [B][H][nsplit][64]
+  float* part_ml;       // [B][H][nsplit][2]
+};
+int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out, hipStream_t stream);
+
+struct DecSeqState {
+  int pos, prompt_len, n_gen, done;
+  int last_tok, pen_tok, last_ts_tok, n_tokens;
+  float sum_logprob, no_speech_prob;
+};
+
+struct DecSelectParams {
+  const float* logits; long ld_logits; int n_vocab;
+  DecSeqState* state;
+  const int* prompt; int max_prompt;
+  int* cur_tok; int* pos;
+  int* gen; int sample_len;
+  int* n_done;
+  const unsigned char* suppress_mask;  // [n_vocab]
+  int eot, blank, no_speech, timestamp_begin, max_initial_ts;
+};
+int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
+int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,
+                         float* x, int B, int D, hipStream_t stream);

@@ -1,0 +1,10 @@
+// elementwise.h -- LayerNorm and small HBM-bound helpers.
+#pragma once
+#include "ccx_common.h"
+
+// y[m][:] = LN(x[m][:]) * gamma + beta, fp32 statistics; out_bf16 and/or out_f32 may be null.
+int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* gamma, const float* beta,
+                         bf16_t* out_bf16, float* out_f32, long ldo, int M, int D, float eps, hipStream_t stream);
+// dst_bf16[i] = bf16(src_f32[i])
+int ccx_launch_f32_to_bf16(ccx_ctx* ctx, const float* src, bf16_t* dst, long n, hipStream_t stream);
+int ccx_launch_fill_u16(ccx_ctx* ctx, bf16_t* dst, bf16_t v, long n, hipStream_t stream);

@@ -1,0 +1,102 @@
+// elementwise.hip -- LayerNorm (fp32 statistics, bf16 output for the following MFMA GEMM) and
+// conversion helpers.  HBM-bound: one wave per row, 16-byte loads, 8/16-byte stores.
+#include "elementwise.h"
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ ob,
+                                                        float* __restrict__ of, long ldo, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* xr = (const float4*)(x + (long)row * ldx);
+  const int nv = D >> 2;  // D % 4 == 0
+  // D <= 1024 -> at most 4 float4 per lane kept in registers
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) { v[i] = xr[idx]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mean = wave_reduce_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_reduce_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float4 g = ((const float4*)gamma)[idx], bb = ((const float4*)beta)[idx];
+      float4 y;
+      y.x = (v[i].x - mean) * rstd * g.x + bb.x;
+      y.y = (v[i].y - mean) * rstd * g.y + bb.y;
+      y.z = (v[i].z - mean) * rstd * g.z + bb.z;
+      y.w = (v[i].w - mean) * rstd * g.w + bb.w;
+      if (ob) {
+        uint2 o;
+        o.x = pack_bf16x2(y.x, y.y);
+        o.y = pack_bf16x2(y.z, y.w);
+        ((uint2*)(ob + (long)row * ldo))[idx] = o;
+      }
+      if (of) ((float4*)(of + (long)row * ldo))[idx] = y;
+    }
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 v = *(const float4*)(src + i);
+    uint2 o;
+    o.x = pack_bf16x2(v.x, v.y);
+    o.y = pack_bf16x2(v.z, v.w);
+    *(uint2*)(dst + i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long j = n & ~3L; j < n; j++) dst[j] = f32_to_bf16(src[j]);
+}
+
+__global__ void fill_u16_kernel(bf16_t* dst, bf16_t v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = v;
+}
+
+int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* gamma, const float* beta,
+                         bf16_t* out_bf16, float* out_f32, long ldo, int M, int D, float eps, hipStream_t stream) {
+  CCX_REQUIRE(ctx, M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+  CCX_REQUIRE(ctx, ldx % 4 == 0 && ldo % 4 == 0, "layernorm: ld must be a multiple of 4");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, ldx, gamma, beta, out_bf16,
+                     out_f32, ldo, M, D, eps);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+int ccx_launch_f32_to_bf16(ccx_ctx* ctx, const float* src, bf16_t* dst, long n, hipStream_t stream) {
+  if (n <= 0) return CCX_OK;
+  CCX_REQUIRE(ctx, ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "f32_to_bf16: misaligned");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((int)blocks), dim3(256), 0, stream, src, dst, n);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+int ccx_launch_fill_u16(ccx_ctx* ctx, bf16_t* dst, bf16_t v, long n, hipStream_t stream) {
+  if (n <= 0) return CCX_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_u16_kernel, dim3((int)blocks), dim3(256), 0, stream, dst, v, n);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}

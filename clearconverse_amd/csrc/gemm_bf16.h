@@ -1,0 +1,40 @@
+// gemm_bf16.h -- bf16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  with fused epilogues.
+// This one kernel family carries every linear / im2col-conv of the hot path
+// (Whisper QKV/out/FFN/logits, conv stem, SepFormer/TDNN projections).
+#pragma once
+#include "ccx_common.h"
+
+enum GemmEpi {
+  EPI_BF16 = 0,        // out bf16 = acc + bias
+  EPI_BF16_GELU = 1,   // out bf16 = gelu(acc + bias)
+  EPI_F32_RESID = 2,   // out f32  = acc + bias + resid[row][n]      (resid may alias out)
+  EPI_F32 = 3,         // out f32  = acc + bias
+  EPI_HEADS = 4,       // q/k (/v) scattered head-major for the attention kernels
+  EPI_BF16_RELU = 5,   // out bf16 = relu(acc + bias)
+  EPI_F32_GELU_POS = 6 // out f32 = gelu(acc + bias) + resid[row % resid_mod][n]   (conv2 + pos-emb)
+};
+
+struct GemmParams {
+  const bf16_t* A;   // [M, K] row-major, leading dimension lda (elements)
+  const bf16_t* W;   // [N, K] row-major (torch Linear layout), leading dimension ldw
+  long lda, ldw;
+  int M, N, K;       // K % 64 == 0; out must have ceil(N/128)*128 writable columns per row
+  const float* bias; // [N] fp32 or nullptr
+  void* out;         // bf16 or f32 depending on epilogue
+  long ldo;
+  const float* resid; // f32
+  long ldr;
+  int resid_mod;     // if > 0: resid row = out_row % resid_mod
+  // output row remap: rows arrive in groups of rpb_in; group g row i -> g*rpb_out + i + roff,
+  // rows with i >= rpb_valid are dropped.  rpb_in == 0 -> identity.
+  int rpb_in, rpb_out, roff, rpb_valid;
+  // EPI_HEADS
+  bf16_t* hq; bf16_t* hk; bf16_t* hv;  // destinations for column blocks 0,1,2 (each d_model wide)
+  int d_model, n_head;   // head_dim fixed to 64
+  int S, Spad;           // rows per sequence (M = B*S), padded sequence length of the destinations
+  int v_transposed;      // 1: third block stored as V^T [B,H,64,Spad]; 0: [B,H,Spad,64]
+  int first_block;       // which destination the first d_model columns go to (0=q,1=k)
+};
+
+// Launch on `stream`.  Returns CCX_OK or an error (message in ctx).
+int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stream);

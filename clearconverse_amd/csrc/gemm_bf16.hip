@@ -1,0 +1,276 @@
+// gemm_bf16.hip -- hand-written CDNA4 bf16 GEMM, C = A * W^T, fp32 accumulate, fused epilogues.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16 accumulators.  Operand tiles go HBM -> LDS with
+// global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), double buffered.  The LDS image
+// is lane-linear (DMA constraint), so the XOR bank swizzle is applied to the per-lane
+// SOURCE address and again on the ds_read_b128 side (cdna_hip_programming.md rule 21).
+// Swizzle keys were chosen with tools/lds_bank_sim.py: both operand reads are
+// conflict-free.
+//
+// The MFMA is issued with operands swapped (W fragment as "A", activation fragment as "B"),
+// so the accumulator holds C^T: each lane owns ONE output row and -- thanks to a row
+// permutation applied when reading W from LDS -- 16 CONSECUTIVE output columns.  The
+// epilogue therefore writes 32 B (bf16) / 64 B (f32) contiguous per lane with no LDS
+// round trip.  For V^T destinations (EPI_HEADS, v_transposed) the un-swapped order is used
+// so each lane owns 4 consecutive ROWS of one column instead.
+#include "gemm_bf16.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES 32768  // A 16 KB + B 16 KB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int keyA(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int keyB(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
+
+template <bool SWAP>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, int m0, int n0,
+                                              f32x4 (&acc)[4][4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- per-lane DMA source rows (loop invariant) ----
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int inst = wave * 4 + i;
+    const int r = inst * 8 + (lane >> 3);
+    const int pc = lane & 7;
+    int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
+    srcA[i] = p.A + (long)gm * p.lda + ((pc ^ keyA(r)) << 3);
+    srcB[i] = p.W + (long)gn * p.ldw + ((pc ^ keyB(r)) << 3);
+  }
+  auto stage = [&](int t, int buf) {
+    char* sA = smem + buf * STAGE_BYTES;
+    char* sB = sA + 16384;
+    const int k0 = t * BK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int inst = wave * 4 + i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sA + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sB + inst * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane LDS read offsets ----
+  const int l15 = lane & 15, h = lane >> 4;
+  const int ka = keyA(l15);                       // rows wr*64 + mt*16 + l15
+  const int q = l15 >> 2, u = l15 & 3;
+  const int kb = ((u >> 1) & 1) | (q << 1);       // rows wc*64 + 16q + 4j + u
+  int offA[2], offB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    offA[ks] = (wr * 64 + l15) * 128 + (((4 * ks + h) ^ ka) << 4);
+    offB[ks] = (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb) << 4);
+  }
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to all waves
+  for (int t = 0; t < nt; t++) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    const char* sA = smem + buf * STAGE_BYTES;
+    const char* sB = sA + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++) a[mt] = *(const bf16x8*)(sA + offA[ks] + mt * 16 * 128);
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = *(const bf16x8*)(sB + offB[ks] + j * 4 * 128);
+#pragma unroll
+      for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (SWAP)
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[mt], acc[mt][j], 0, 0, 0);
+          else
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], acc[mt][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& valid) {
+  if (p.rpb_in <= 0) { valid = true; return m; }
+  const int g = m / p.rpb_in, i = m - g * p.rpb_in;
+  valid = i < p.rpb_valid;
+  return (long)g * p.rpb_out + i + p.roff;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + BN - 1) / BN;
+  // XCD-aware bijective remap (blocks b, b+8 share an XCD/L2): give each XCD a contiguous
+  // run of tiles so the A row-panel and the (small) W are re-read from that XCD's L2.
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (EPI == EPI_HEADS) {
+    const int blk = n0 / p.d_model + p.first_block;  // 0=q 1=k 2=v  (d_model % 128 == 0)
+    if (blk == 2 && p.v_transposed) {
+      gemm_mainloop<false>(p, smem, m0, n0, acc);
+      // lane: column n = n0 + wc*64 + 16q + 4j + u ; rows m0 + wr*64 + mt*16 + 4h + reg
+      const int q = l15 >> 2, u = l15 & 3;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int n = n0 + wc * 64 + 16 * q + 4 * j + u;
+        const int nn = n % p.d_model, hh = nn >> 6, d = nn & 63;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+          const int m = m0 + wr * 64 + mt * 16 + 4 * h;
+          if (m < p.M) {
+            const int b = m / p.S, s = m - b * p.S;
+            bf16_t* dst = p.hv + ((long)(b * p.n_head + hh) * 64 + d) * p.Spad + s;
+            uint2 v;
+            v.x = pack_bf16x2(acc[mt][j][0] + bv, acc[mt][j][1] + bv);
+            v.y = pack_bf16x2(acc[mt][j][2] + bv, acc[mt][j][3] + bv);
+            *(uint2*)dst = v;
+          }
+        }
+      }
+      return;
+    }
+  }
+
+  gemm_mainloop<true>(p, smem, m0, n0, acc);
+
+  // lane: row m = m0 + wr*64 + mt*16 + l15 ; columns nb .. nb+15, value index 4j+reg
+  const int nb = n0 + wc * 64 + 16 * h;
+  float bias[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) bias[i] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) bias[i] = (nb + i < p.N) ? p.bias[nb + i] : 0.f;
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; mt++) {
+    const int m = m0 + wr * 64 + mt * 16 + l15;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
+
+    if (EPI == EPI_HEADS) {
+      const int blk = nb / p.d_model + p.first_block;
+      const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
+      const int b = m / p.S, s = m - b * p.S;
+      bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
+      bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
+      uint4 o0, o1;
+      o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+      o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+      o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+      o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+      ((uint4*)dst)[0] = o0;
+      ((uint4*)dst)[1] = o1;
+      continue;
+    }
+
+    bool valid;
+    const long orow = remap_row(p, m, valid);
+    if (!valid) continue;
+
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU) {
+      if (EPI == EPI_BF16_GELU) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
+      }
+      if (EPI == EPI_BF16_RELU) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
+      }
+      bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
+      uint4 o0, o1;
+      o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+      o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+      o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+      o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+      ((uint4*)dst)[0] = o0;
+      ((uint4*)dst)[1] = o1;
+    } else {
+      if (EPI == EPI_F32_GELU_POS) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
+      }
+      if (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
+        const long rrow = p.resid_mod > 0 ? (orow % p.resid_mod) : orow;
+        const float4* rp = (const float4*)(p.resid + rrow * p.ldr + nb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float4 r4 = rp[i];
+          v[4 * i + 0] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+        }
+      }
+      float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+  }
+}
+
+template <int EPI>
+static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+  const int tiles = ccx_cdiv(p.M, BM) * ccx_cdiv(p.N, BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stream) {
+  CCX_REQUIRE(ctx, p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+  CCX_REQUIRE(ctx, p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+  CCX_REQUIRE(ctx, p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
+  CCX_REQUIRE(ctx, ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: A/W must be 16-byte aligned");
+  if (epi == EPI_HEADS) {
+    CCX_REQUIRE(ctx, p.d_model % 128 == 0 && p.S > 0 && p.S % 4 == 0 && p.Spad >= p.S && p.Spad % 8 == 0,
+                "gemm heads: bad d_model/S/Spad");
+    CCX_REQUIRE(ctx, p.N % 128 == 0, "gemm heads: N must be a multiple of 128");
+  } else {
+    CCX_REQUIRE(ctx, p.out != nullptr && p.ldo % 8 == 0, "gemm: out null or ldo not a multiple of 8");
+    CCX_REQUIRE(ctx, p.ldo >= (long)ccx_cdiv(p.N, BN) * BN, "gemm: ldo=%ld must cover N rounded up to 128", p.ldo);
+  }
+  switch (epi) {
+    case EPI_BF16: return launch_epi<EPI_BF16>(ctx, p, stream);
+    case EPI_BF16_GELU: return launch_epi<EPI_BF16_GELU>(ctx, p, stream);
+    case EPI_BF16_RELU: return launch_epi<EPI_BF16_RELU>(ctx, p, stream);
+    case EPI_F32_RESID: return launch_epi<EPI_F32_RESID>(ctx, p, stream);
+    case EPI_F32: return launch_epi<EPI_F32>(ctx, p, stream);
+    case EPI_HEADS: return launch_epi<EPI_HEADS>(ctx, p, stream);
+    case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(ctx, p, stream);
+  }
+  return ccx_fail(ctx, CCX_ERR_ARG, "gemm: unknown epilogue %d", epi);
+}

@@ -1,0 +1,737 @@
+// whisper.hip -- Whisper model object of libccx: weight intake by openai-whisper state_dict names,
+// encoder forward (conv stem as im2col MFMA GEMMs, 12 pre-LN transformer blocks, cross-KV
+// projection) and greedy decoding (device-side state machine, step chain captured in a hipGraph).
+//
+// Replaces `self.whisper_model` of the reference (loaded at back/api.py:665-703, called at
+// back/api.py:1286-1292, 1432-1438, 1474-1480).  Model semantics follow openai-whisper
+// model.py / decoding.py [UPSTREAM-RECALL -- not vendored in the reference]; the CPU restatement
+// the tests compare against is oracle/whisper_ref.py.
+#include <map>
+#include <math.h>
+#include "../../include/ccx.h"
+#include "attention.h"
+#include "ccx_common.h"
+#include "decoder.h"
+#include "elementwise.h"
+#include "gemm_bf16.h"
+#include "logmel.h"
+
+namespace {
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+inline bf16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+inline float host_half_to_f32(uint16_t h) {
+  const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) u = s << 31;
+    else {
+      int ee = -1; uint32_t mm = m;
+      do { ee++; mm <<= 1; } while (!(mm & 0x400));
+      u = (s << 31) | ((uint32_t)(127 - 15 - ee) << 23) | ((mm & 0x3ff) << 13);
+    }
+  } else if (e == 31) u = (s << 31) | 0x7f800000u | (m << 13);
+  else u = (s << 31) | ((e + 112) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct EncLayer {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  bf16_t *Wqkv, *Wo, *W1, *W2;
+  float *bqkv, *bo, *b1, *b2;
+};
+struct DecLayer {
+  float *ln1_g, *ln1_b, *lnc_g, *lnc_b, *ln2_g, *ln2_b;
+  bf16_t *Wqkv, *Wo, *Wcq, *Wckv, *Wco, *W1, *W2;
+  float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
+  bf16_t *crossK, *crossV, *selfK, *selfV;
+};
+
+}  // namespace
+
+struct ccx_whisper {
+  ccx_ctx* ctx = nullptr;
+  ccx_whisper_dims d{};
+  int max_batch = 0;
+  bool finalized = false;
+  std::map<std::string, HostTensor> staged;
+  std::vector<void*> allocs;
+
+  // derived sizes
+  int Spad = 0;    // padded audio context (multiple of 128)
+  int Vpad = 0;    // vocab rounded up to 128
+  int Fraw = 3008; // frames computed by the log-mel pass (covers 30 s + reflect tail)
+  static constexpr int kCrossSplitMax = 8;
+
+  // tables
+  LogmelTables lm{};
+  // encoder weights
+  bf16_t *Wc1 = nullptr, *Wc2 = nullptr;
+  float *bc1 = nullptr, *bc2 = nullptr, *enc_pos = nullptr, *lnp_g = nullptr, *lnp_b = nullptr;
+  std::vector<EncLayer> enc;
+  // decoder weights
+  float *tok_emb_f32 = nullptr, *dec_pos = nullptr, *lnd_g = nullptr, *lnd_b = nullptr;
+  bf16_t* tok_emb_bf16 = nullptr;
+  std::vector<DecLayer> dec;
+  // rules
+  ccx_decode_rules rules{};
+  unsigned char* suppress_mask = nullptr;
+  bool rules_set = false;
+
+  // workspaces (encoder)
+  float* lm_raw = nullptr; unsigned int* lm_max = nullptr; int *lm_n = nullptr, *lm_seek = nullptr, *lm_seg = nullptr;
+  bf16_t *im2col = nullptr, *h1 = nullptr, *xn = nullptr, *qb = nullptr, *kb = nullptr, *vtb = nullptr, *attn = nullptr,
+         *ffn = nullptr, *xa = nullptr;
+  float* x = nullptr;
+  // workspaces (decoder)
+  float *dx = nullptr, *dq = nullptr, *dlogits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  bf16_t *dattn = nullptr, *dffn = nullptr;
+  int *cur_tok = nullptr, *pos = nullptr, *prompt = nullptr, *gen = nullptr, *n_done = nullptr;
+  DecSeqState* state = nullptr;
+  int max_prompt_cap = 0, sample_cap = 0;
+  // graph cache
+  std::map<int, hipGraphExec_t> graphs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(ccx_whisper* w, T** out, size_t count, bool zero) {
+  void* p = nullptr;
+  const size_t bytes = ccx_align(count * sizeof(T), 256);
+  CCX_HIP(w->ctx, hipMalloc(&p, bytes));
+  if (zero) CCX_HIP(w->ctx, hipMemset(p, 0, bytes));
+  w->allocs.push_back(p);
+  *out = (T*)p;
+  return CCX_OK;
+}
+
+int up_f32(ccx_whisper* w, float** out, const float* src, size_t n) {
+  int rc = dev_alloc(w, out, n, false);
+  if (rc) return rc;
+  CCX_HIP(w->ctx, hipMemcpy(*out, src, n * 4, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+int up_bf16(ccx_whisper* w, bf16_t** out, const float* src, size_t n) {
+  std::vector<bf16_t> tmp(n);
+  for (size_t i = 0; i < n; i++) tmp[i] = host_f32_to_bf16(src[i]);
+  int rc = dev_alloc(w, out, n, false);
+  if (rc) return rc;
+  CCX_HIP(w->ctx, hipMemcpy(*out, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+
+const HostTensor* find(ccx_whisper* w, const std::string& name) {
+  auto it = w->staged.find(name);
+  return it == w->staged.end() ? nullptr : &it->second;
+}
+
+int need(ccx_whisper* w, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+  const HostTensor* t = find(w, name);
+  if (!t) return ccx_fail(w->ctx, CCX_ERR_MISSING, "whisper: tensor '%s' was never set", name.c_str());
+  if (t->shape != shape) {
+    std::string got, want;
+    for (auto v : t->shape) got += std::to_string(v) + ",";
+    for (auto v : shape) want += std::to_string(v) + ",";
+    return ccx_fail(w->ctx, CCX_ERR_ARG, "whisper: tensor '%s' has shape [%s] expected [%s]", name.c_str(), got.c_str(),
+                    want.c_str());
+  }
+  *out = t;
+  return CCX_OK;
+}
+
+#define NEED(var, name, ...)                                              \
+  const HostTensor* var = nullptr;                                        \
+  {                                                                       \
+    int _rc = need(w, (name), std::vector<int64_t>{__VA_ARGS__}, &var);   \
+    if (_rc) return _rc;                                                  \
+  }
+#define TRY(expr)            \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc) return _rc;     \
+  } while (0)
+
+// conv weight [out][in][3] -> GEMM weight [out][Kpad] with k = tap*in + c
+std::vector<float> conv_to_gemm(const HostTensor& t, int Kpad) {
+  const int64_t O = t.shape[0], I = t.shape[1], T = t.shape[2];
+  std::vector<float> r((size_t)O * Kpad, 0.f);
+  for (int64_t o = 0; o < O; o++)
+    for (int64_t c = 0; c < I; c++)
+      for (int64_t k = 0; k < T; k++) r[(size_t)o * Kpad + k * I + c] = t.data[(o * I + c) * T + k];
+  return r;
+}
+
+int build_logmel_tables(ccx_whisper* w) {
+  NEED(mf, "mel_filters", w->d.n_mels, 201);
+  CCX_REQUIRE(w->ctx, w->d.n_mels == 80, "whisper: only n_mels == 80 is supported (got %d)", w->d.n_mels);
+  std::vector<float> c(400 * 208, 0.f), s(400 * 208, 0.f), fb(80 * 208, 0.f);
+  std::vector<int> rg(160);
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int n = 0; n < 400; n++) {
+    const double win = 0.5 - 0.5 * cos(two_pi * n / 400.0);  // periodic Hann (torch.hann_window default)
+    for (int k = 0; k < 201; k++) {
+      const int ph = (int)(((long)n * k) % 400);  // exact phase reduction
+      const double a = two_pi * ph / 400.0;
+      c[n * 208 + k] = (float)(cos(a) * win);
+      s[n * 208 + k] = (float)(sin(a) * win);
+    }
+  }
+  for (int m = 0; m < 80; m++) {
+    int k0 = 201, k1 = 0;
+    for (int k = 0; k < 201; k++) {
+      const float v = mf->data[m * 201 + k];
+      fb[m * 208 + k] = v;
+      if (v != 0.f) { if (k < k0) k0 = k; k1 = k + 1; }
+    }
+    if (k1 == 0) { k0 = 0; k1 = 0; }
+    rg[2 * m] = k0; rg[2 * m + 1] = k1;
+  }
+  float *dc, *ds, *dfb; int* drg;
+  TRY(up_f32(w, &dc, c.data(), c.size()));
+  TRY(up_f32(w, &ds, s.data(), s.size()));
+  TRY(up_f32(w, &dfb, fb.data(), fb.size()));
+  TRY(dev_alloc(w, &drg, 160, false));
+  CCX_HIP(w->ctx, hipMemcpy(drg, rg.data(), 160 * 4, hipMemcpyHostToDevice));
+  w->lm.dft_cos = dc; w->lm.dft_sin = ds; w->lm.mel_fb = dfb; w->lm.mel_range = drg;
+  return CCX_OK;
+}
+
+std::vector<float> cat_rows(std::initializer_list<const std::vector<float>*> parts) {
+  std::vector<float> r;
+  for (auto p : parts) r.insert(r.end(), p->begin(), p->end());
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch, ccx_whisper** out) {
+  if (!ctx) return CCX_ERR_ARG;
+  CCX_REQUIRE(ctx, dims && out, "ccx_whisper_create: null argument");
+  CCX_REQUIRE(ctx, max_batch >= 1 && max_batch <= 1024, "ccx_whisper_create: max_batch %d out of range", max_batch);
+  const ccx_whisper_dims& d = *dims;
+  CCX_REQUIRE(ctx, d.n_audio_state % 128 == 0 && d.n_text_state == d.n_audio_state, "whisper: n_state must be a multiple of 128 and equal for encoder/decoder");
+  CCX_REQUIRE(ctx, d.n_audio_state / d.n_audio_head == 64 && d.n_text_state / d.n_text_head == 64, "whisper: head_dim must be 64");
+  CCX_REQUIRE(ctx, d.n_audio_state <= 1024, "whisper: n_state > 1024 not supported yet");
+  CCX_REQUIRE(ctx, d.n_audio_ctx == 1500 && d.n_mels == 80, "whisper: n_audio_ctx must be 1500 and n_mels 80");
+  CCX_REQUIRE(ctx, d.n_audio_ctx % 4 == 0, "whisper: n_audio_ctx must be a multiple of 4");
+  ccx_whisper* w = new ccx_whisper();
+  w->ctx = ctx;
+  w->d = d;
+  w->max_batch = max_batch;
+  w->Spad = ccx_cdiv(d.n_audio_ctx, 128) * 128;
+  w->Vpad = ccx_cdiv(d.n_vocab, 128) * 128;
+  *out = w;
+  return CCX_OK;
+}
+
+void ccx_whisper_destroy(ccx_whisper* w) {
+  if (!w) return;
+  for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
+  for (void* p : w->allocs) hipFree(p);
+  delete w;
+}
+
+int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, int dtype, int ndim, const int64_t* shape) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, !w->finalized, "whisper: set_tensor after finalize");
+  CCX_REQUIRE(w->ctx, name && data && ndim >= 1 && ndim <= 4 && shape, "whisper: set_tensor bad arguments");
+  const std::string nm(name);
+  const bool known = nm == "mel_filters" || nm.rfind("encoder.", 0) == 0 || nm.rfind("decoder.", 0) == 0;
+  CCX_REQUIRE(w->ctx, known, "whisper: unknown tensor name '%s'", name);
+  size_t n = 1;
+  HostTensor t;
+  for (int i = 0; i < ndim; i++) { CCX_REQUIRE(w->ctx, shape[i] > 0, "whisper: '%s' has an empty dim", name); n *= (size_t)shape[i]; t.shape.push_back(shape[i]); }
+  t.data.resize(n);
+  if (dtype == CCX_DTYPE_F32) {
+    CCX_HIP(w->ctx, hipMemcpy(t.data.data(), data, n * 4, hipMemcpyDefault));
+  } else if (dtype == CCX_DTYPE_BF16 || dtype == CCX_DTYPE_F16) {
+    std::vector<uint16_t> tmp(n);
+    CCX_HIP(w->ctx, hipMemcpy(tmp.data(), data, n * 2, hipMemcpyDefault));
+    for (size_t i = 0; i < n; i++) {
+      if (dtype == CCX_DTYPE_BF16) { uint32_t u = (uint32_t)tmp[i] << 16; memcpy(&t.data[i], &u, 4); }
+      else t.data[i] = host_half_to_f32(tmp[i]);
+    }
+  } else {
+    return ccx_fail(w->ctx, CCX_ERR_ARG, "whisper: set_tensor dtype %d unsupported", dtype);
+  }
+  w->staged[nm] = std::move(t);
+  return CCX_OK;
+}
+
+int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* r) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, r, "whisper: rules null");
+  const int V = w->d.n_vocab;
+  CCX_REQUIRE(w->ctx, r->eot >= 0 && r->eot < V && r->sot < V && r->no_speech < V && r->timestamp_begin <= V && r->blank < V &&
+                          r->no_timestamps < V, "whisper: rule token id out of range");
+  std::vector<unsigned char> mask(V, 0);
+  for (int i = 0; i < r->n_suppress; i++) {
+    CCX_REQUIRE(w->ctx, r->suppress[i] >= 0 && r->suppress[i] < V, "whisper: suppress id %d out of range", r->suppress[i]);
+    mask[r->suppress[i]] = 1;
+  }
+  if (r->no_timestamps >= 0) mask[r->no_timestamps] = 1;  // ApplyTimestampRules bans <|notimestamps|>
+  if (!w->suppress_mask) TRY(dev_alloc(w, &w->suppress_mask, (size_t)V, false));
+  CCX_HIP(w->ctx, hipMemcpy(w->suppress_mask, mask.data(), V, hipMemcpyHostToDevice));
+  w->rules = *r;
+  w->rules.suppress = nullptr;
+  w->rules_set = true;
+  return CCX_OK;
+}
+
+int ccx_whisper_finalize(ccx_whisper* w) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, !w->finalized, "whisper: finalize called twice");
+  CCX_HIP(w->ctx, hipSetDevice(w->ctx->device));
+  const ccx_whisper_dims& d = w->d;
+  const int D = d.n_audio_state, F = 4 * D, B = w->max_batch, S = d.n_audio_ctx, H = d.n_audio_head;
+  TRY(build_logmel_tables(w));
+
+  // ---------------- encoder ----------------
+  {
+    NEED(c1w, "encoder.conv1.weight", D, d.n_mels, 3);
+    NEED(c1b, "encoder.conv1.bias", D);
+    NEED(c2w, "encoder.conv2.weight", D, D, 3);
+    NEED(c2b, "encoder.conv2.bias", D);
+    NEED(pe, "encoder.positional_embedding", S, D);
+    NEED(lg, "encoder.ln_post.weight", D);
+    NEED(lb, "encoder.ln_post.bias", D);
+    std::vector<float> g1 = conv_to_gemm(*c1w, 256), g2 = conv_to_gemm(*c2w, 3 * D);
+    TRY(up_bf16(w, &w->Wc1, g1.data(), g1.size()));
+    TRY(up_bf16(w, &w->Wc2, g2.data(), g2.size()));
+    TRY(up_f32(w, &w->bc1, c1b->data.data(), D));
+    TRY(up_f32(w, &w->bc2, c2b->data.data(), D));
+    TRY(up_f32(w, &w->enc_pos, pe->data.data(), (size_t)S * D));
+    TRY(up_f32(w, &w->lnp_g, lg->data.data(), D));
+    TRY(up_f32(w, &w->lnp_b, lb->data.data(), D));
+  }
+  w->enc.resize(d.n_audio_layer);
+  const std::vector<float> zerosD(D, 0.f);
+  for (int l = 0; l < d.n_audio_layer; l++) {
+    const std::string p = "encoder.blocks." + std::to_string(l) + ".";
+    EncLayer& L = w->enc[l];
+    NEED(qw, p + "attn.query.weight", D, D); NEED(qbias, p + "attn.query.bias", D);
+    NEED(kw, p + "attn.key.weight", D, D);
+    NEED(vw, p + "attn.value.weight", D, D); NEED(vbias, p + "attn.value.bias", D);
+    NEED(ow, p + "attn.out.weight", D, D); NEED(obias, p + "attn.out.bias", D);
+    NEED(l1g, p + "attn_ln.weight", D); NEED(l1b, p + "attn_ln.bias", D);
+    NEED(m0w, p + "mlp.0.weight", F, D); NEED(m0b, p + "mlp.0.bias", F);
+    NEED(m2w, p + "mlp.2.weight", D, F); NEED(m2b, p + "mlp.2.bias", D);
+    NEED(l2g, p + "mlp_ln.weight", D); NEED(l2b, p + "mlp_ln.bias", D);
+    std::vector<float> wqkv = cat_rows({&qw->data, &kw->data, &vw->data});
+    std::vector<float> bqkv = cat_rows({&qbias->data, &zerosD, &vbias->data});
+    TRY(up_bf16(w, &L.Wqkv, wqkv.data(), wqkv.size())); TRY(up_f32(w, &L.bqkv, bqkv.data(), bqkv.size()));
+    TRY(up_bf16(w, &L.Wo, ow->data.data(), ow->data.size())); TRY(up_f32(w, &L.bo, obias->data.data(), D));
+    TRY(up_bf16(w, &L.W1, m0w->data.data(), m0w->data.size())); TRY(up_f32(w, &L.b1, m0b->data.data(), F));
+    TRY(up_bf16(w, &L.W2, m2w->data.data(), m2w->data.size())); TRY(up_f32(w, &L.b2, m2b->data.data(), D));
+    TRY(up_f32(w, &L.ln1_g, l1g->data.data(), D)); TRY(up_f32(w, &L.ln1_b, l1b->data.data(), D));
+    TRY(up_f32(w, &L.ln2_g, l2g->data.data(), D)); TRY(up_f32(w, &L.ln2_b, l2b->data.data(), D));
+  }
+
+  // ---------------- decoder ----------------
+  {
+    NEED(te, "decoder.token_embedding.weight", d.n_vocab, D);
+    NEED(pe, "decoder.positional_embedding", d.n_text_ctx, D);
+    NEED(lg, "decoder.ln.weight", D);
+    NEED(lb, "decoder.ln.bias", D);
+    TRY(up_f32(w, &w->tok_emb_f32, te->data.data(), te->data.size()));
+    TRY(up_bf16(w, &w->tok_emb_bf16, te->data.data(), te->data.size()));
+    TRY(up_f32(w, &w->dec_pos, pe->data.data(), pe->data.size()));
+    TRY(up_f32(w, &w->lnd_g, lg->data.data(), D));
+    TRY(up_f32(w, &w->lnd_b, lb->data.data(), D));
+  }
+  w->dec.resize(d.n_text_layer);
+  const int Tc = d.n_text_ctx;
+  for (int l = 0; l < d.n_text_layer; l++) {
+    const std::string p = "decoder.blocks." + std::to_string(l) + ".";
+    DecLayer& L = w->dec[l];
+    NEED(qw, p + "attn.query.weight", D, D); NEED(qbias, p + "attn.query.bias", D);
+    NEED(kw, p + "attn.key.weight", D, D);
+    NEED(vw, p + "attn.value.weight", D, D); NEED(vbias, p + "attn.value.bias", D);
+    NEED(ow, p + "attn.out.weight", D, D); NEED(obias, p + "attn.out.bias", D);
+    NEED(l1g, p + "attn_ln.weight", D); NEED(l1b, p + "attn_ln.bias", D);
+    NEED(cqw, p + "cross_attn.query.weight", D, D); NEED(cqb, p + "cross_attn.query.bias", D);
+    NEED(ckw, p + "cross_attn.key.weight", D, D);
+    NEED(cvw, p + "cross_attn.value.weight", D, D); NEED(cvb, p + "cross_attn.value.bias", D);
+    NEED(cow, p + "cross_attn.out.weight", D, D); NEED(cob, p + "cross_attn.out.bias", D);
+    NEED(lcg, p + "cross_attn_ln.weight", D); NEED(lcb, p + "cross_attn_ln.bias", D);
+    NEED(m0w, p + "mlp.0.weight", F, D); NEED(m0b, p + "mlp.0.bias", F);
+    NEED(m2w, p + "mlp.2.weight", D, F); NEED(m2b, p + "mlp.2.bias", D);
+    NEED(l2g, p + "mlp_ln.weight", D); NEED(l2b, p + "mlp_ln.bias", D);
+    std::vector<float> wqkv = cat_rows({&qw->data, &kw->data, &vw->data});
+    std::vector<float> bqkv = cat_rows({&qbias->data, &zerosD, &vbias->data});
+    std::vector<float> wckv = cat_rows({&ckw->data, &cvw->data});
+    std::vector<float> bckv = cat_rows({&zerosD, &cvb->data});
+    TRY(up_bf16(w, &L.Wqkv, wqkv.data(), wqkv.size())); TRY(up_f32(w, &L.bqkv, bqkv.data(), bqkv.size()));
+    TRY(up_bf16(w, &L.Wo, ow->data.data(), ow->data.size())); TRY(up_f32(w, &L.bo, obias->data.data(), D));
+    TRY(up_bf16(w, &L.Wcq, cqw->data.data(), cqw->data.size())); TRY(up_f32(w, &L.bcq, cqb->data.data(), D));
+    TRY(up_bf16(w, &L.Wckv, wckv.data(), wckv.size())); TRY(up_f32(w, &L.bckv, bckv.data(), bckv.size()));
+    TRY(up_bf16(w, &L.Wco, cow->data.data(), cow->data.size())); TRY(up_f32(w, &L.bco, cob->data.data(), D));
+    TRY(up_bf16(w, &L.W1, m0w->data.data(), m0w->data.size())); TRY(up_f32(w, &L.b1, m0b->data.data(), F));
+    TRY(up_bf16(w, &L.W2, m2w->data.data(), m2w->data.size())); TRY(up_f32(w, &L.b2, m2b->data.data(), D));
+    TRY(up_f32(w, &L.ln1_g, l1g->data.data(), D)); TRY(up_f32(w, &L.ln1_b, l1b->data.data(), D));
+    TRY(up_f32(w, &L.lnc_g, lcg->data.data(), D)); TRY(up_f32(w, &L.lnc_b, lcb->data.data(), D));
+    TRY(up_f32(w, &L.ln2_g, l2g->data.data(), D)); TRY(up_f32(w, &L.ln2_b, l2b->data.data(), D));
+    const size_t ck = (size_t)B * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
+    TRY(dev_alloc(w, &L.crossK, ck, true)); TRY(dev_alloc(w, &L.crossV, ck, true));
+    TRY(dev_alloc(w, &L.selfK, sk, true)); TRY(dev_alloc(w, &L.selfV, sk, true));
+  }
+  w->staged.clear();
+
+  // ---------------- workspaces ----------------
+  TRY(dev_alloc(w, &w->lm_raw, (size_t)B * 80 * w->Fraw, true));
+  TRY(dev_alloc(w, &w->lm_max, (size_t)B, true));
+  TRY(dev_alloc(w, &w->lm_n, (size_t)B, true));
+  TRY(dev_alloc(w, &w->lm_seek, (size_t)B, true));
+  TRY(dev_alloc(w, &w->lm_seg, (size_t)B, true));
+  TRY(dev_alloc(w, &w->im2col, (size_t)B * 3000 * 256, true));
+  TRY(dev_alloc(w, &w->h1, ((size_t)B * 3002 + 2) * D, true));
+  TRY(dev_alloc(w, &w->x, (size_t)B * S * D, true));
+  TRY(dev_alloc(w, &w->xn, (size_t)B * S * D, true));
+  TRY(dev_alloc(w, &w->xa, (size_t)B * S * D, true));
+  TRY(dev_alloc(w, &w->qb, (size_t)B * H * w->Spad * 64, true));
+  TRY(dev_alloc(w, &w->kb, (size_t)B * H * w->Spad * 64, true));
+  TRY(dev_alloc(w, &w->vtb, (size_t)B * H * 64 * w->Spad, true));
+  TRY(dev_alloc(w, &w->attn, (size_t)B * S * D, true));
+  TRY(dev_alloc(w, &w->ffn, (size_t)B * S * F, true));
+
+  TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
+  TRY(dev_alloc(w, &w->dq, (size_t)B * D, true));
+  TRY(dev_alloc(w, &w->dattn, (size_t)B * D, true));
+  TRY(dev_alloc(w, &w->dffn, (size_t)B * F, true));
+  TRY(dev_alloc(w, &w->dlogits, (size_t)B * w->Vpad, true));
+  TRY(dev_alloc(w, &w->part_o, (size_t)B * H * ccx_whisper::kCrossSplitMax * 64, true));
+  TRY(dev_alloc(w, &w->part_ml, (size_t)B * H * ccx_whisper::kCrossSplitMax * 2, true));
+  TRY(dev_alloc(w, &w->cur_tok, (size_t)B, true));
+  TRY(dev_alloc(w, &w->pos, (size_t)B, true));
+  TRY(dev_alloc(w, &w->n_done, (size_t)4, true));
+  TRY(dev_alloc(w, &w->state, (size_t)B, true));
+  w->max_prompt_cap = d.n_text_ctx;
+  w->sample_cap = d.n_text_ctx;
+  TRY(dev_alloc(w, &w->prompt, (size_t)B * w->max_prompt_cap, true));
+  TRY(dev_alloc(w, &w->gen, (size_t)B * w->sample_cap, true));
+  w->finalized = true;
+  return CCX_OK;
+}
+
+int ccx_whisper_logmel(ccx_whisper* w, const float* audio, int64_t stride, const int* n_samples, const int* seek, int B,
+                       float* mel_out, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  CCX_REQUIRE(w->ctx, w->finalized, "whisper: not finalized");
+  CCX_REQUIRE(w->ctx, audio && n_samples && B >= 1 && B <= w->max_batch, "whisper_logmel: bad arguments (B=%d, max %d)", B, w->max_batch);
+  for (int b = 0; b < B; b++) {
+    CCX_REQUIRE(w->ctx, n_samples[b] >= 0 && n_samples[b] <= stride, "whisper_logmel: n_samples[%d]=%d exceeds stride", b, n_samples[b]);
+    const int s = seek ? seek[b] : 0;
+    // frames that touch audio content must lie inside the computed range
+    const long need_frames = ((long)n_samples[b] + 200 + 159) / 160 + 1;
+    CCX_REQUIRE(w->ctx, need_frames <= w->Fraw, "whisper_logmel: clip %d (%d samples) is longer than one 30 s window; split it on the host", b, n_samples[b]);
+    CCX_REQUIRE(w->ctx, s >= 0, "whisper_logmel: negative seek");
+  }
+  // segment_size = min(N_FRAMES, content_frames - seek), content_frames = n_samples // 160 (transcribe.py)
+  std::vector<int> seg(B), sk(B);
+  for (int b = 0; b < B; b++) {
+    sk[b] = seek ? seek[b] : 0;
+    int sl = n_samples[b] / 160 - sk[b];
+    seg[b] = sl < 0 ? 0 : (sl > 3000 ? 3000 : sl);
+  }
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->lm_n, n_samples, B * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->lm_seek, sk.data(), B * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->lm_seg, seg.data(), B * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host staging vectors go out of scope
+  return ccx_launch_logmel(w->ctx, w->lm, audio, stride, w->lm_n, w->lm_seek, w->lm_seg, B, w->Fraw, w->lm_raw,
+                           w->lm_max, mel_out, w->im2col, stream);
+}
+
+__global__ void mel_to_im2col_kernel(const float* __restrict__ mel, bf16_t* __restrict__ im2col) {
+  // mel [B][80][3000] -> im2col [B*3000][256], k = tap*80 + c holds frame t-1+tap
+  const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 8), k = threadIdx.x & 255;
+  if (t >= 3000) return;
+  float v = 0.f;
+  if (k < 240) {
+    const int tap = k / 80, c = k - tap * 80, fr = t - 1 + tap;
+    if (fr >= 0 && fr < 3000) v = mel[((long)b * 80 + c) * 3000 + fr];
+  }
+  im2col[((long)b * 3000 + t) * 256 + k] = f32_to_bf16(v);
+}
+
+int ccx_whisper_set_mel(ccx_whisper* w, const float* mel, int B, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, w->finalized && mel && B >= 1 && B <= w->max_batch, "whisper_set_mel: bad arguments");
+  hipLaunchKernelGGL(mel_to_im2col_kernel, dim3(750, B), dim3(1024), 0, (hipStream_t)stream_, mel, w->im2col);
+  CCX_CHECK_LAUNCH(w->ctx);
+  return CCX_OK;
+}
+
+int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  ccx_ctx* ctx = w->ctx;
+  CCX_REQUIRE(ctx, w->finalized, "whisper: not finalized");
+  CCX_REQUIRE(ctx, B >= 1 && B <= w->max_batch, "whisper_encode: B=%d out of range (max %d)", B, w->max_batch);
+  const ccx_whisper_dims& d = w->d;
+  const int D = d.n_audio_state, F = 4 * D, S = d.n_audio_ctx, H = d.n_audio_head;
+  GemmParams p;
+  // conv1 + GELU: [B*3000,256] x [D,256]^T -> h1 rows b*3002 + 1 + t
+  memset(&p, 0, sizeof(p));
+  p.A = w->im2col; p.lda = 256; p.W = w->Wc1; p.ldw = 256; p.M = B * 3000; p.N = D; p.K = 256;
+  p.bias = w->bc1; p.out = w->h1; p.ldo = D; p.rpb_in = 3000; p.rpb_out = 3002; p.roff = 1; p.rpb_valid = 3000;
+  TRY(ccx_launch_gemm(ctx, EPI_BF16_GELU, p, stream));
+  // conv2 (stride 2) + GELU + positional embedding: row m' = b*1501 + t reads h1 rows 2m' .. 2m'+2
+  memset(&p, 0, sizeof(p));
+  p.A = w->h1; p.lda = 2 * D; p.W = w->Wc2; p.ldw = 3 * D; p.M = B * 1501; p.N = D; p.K = 3 * D;
+  p.bias = w->bc2; p.out = w->x; p.ldo = D; p.resid = w->enc_pos; p.ldr = D; p.resid_mod = S;
+  p.rpb_in = 1501; p.rpb_out = S; p.roff = 0; p.rpb_valid = S;
+  TRY(ccx_launch_gemm(ctx, EPI_F32_GELU_POS, p, stream));
+
+  const int M = B * S;
+  for (int l = 0; l < d.n_audio_layer; l++) {
+    const EncLayer& L = w->enc[l];
+    TRY(ccx_launch_layernorm(ctx, w->x, D, L.ln1_g, L.ln1_b, w->xn, nullptr, D, M, D, 1e-5f, stream));
+    memset(&p, 0, sizeof(p));
+    p.A = w->xn; p.lda = D; p.W = L.Wqkv; p.ldw = D; p.M = M; p.N = 3 * D; p.K = D; p.bias = L.bqkv;
+    p.hq = w->qb; p.hk = w->kb; p.hv = w->vtb; p.d_model = D; p.n_head = H; p.S = S; p.Spad = w->Spad; p.v_transposed = 1;
+    TRY(ccx_launch_gemm(ctx, EPI_HEADS, p, stream));
+    TRY(ccx_launch_enc_attention(ctx, w->qb, w->kb, w->vtb, w->attn, B, H, S, w->Spad, stream));
+    memset(&p, 0, sizeof(p));
+    p.A = w->attn; p.lda = D; p.W = L.Wo; p.ldw = D; p.M = M; p.N = D; p.K = D; p.bias = L.bo;
+    p.out = w->x; p.ldo = D; p.resid = w->x; p.ldr = D;
+    TRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, stream));
+    TRY(ccx_launch_layernorm(ctx, w->x, D, L.ln2_g, L.ln2_b, w->xn, nullptr, D, M, D, 1e-5f, stream));
+    memset(&p, 0, sizeof(p));
+    p.A = w->xn; p.lda = D; p.W = L.W1; p.ldw = D; p.M = M; p.N = F; p.K = D; p.bias = L.b1; p.out = w->ffn; p.ldo = F;
+    TRY(ccx_launch_gemm(ctx, EPI_BF16_GELU, p, stream));
+    memset(&p, 0, sizeof(p));
+    p.A = w->ffn; p.lda = F; p.W = L.W2; p.ldw = F; p.M = M; p.N = D; p.K = F; p.bias = L.b2;
+    p.out = w->x; p.ldo = D; p.resid = w->x; p.ldr = D;
+    TRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, stream));
+  }
+  TRY(ccx_launch_layernorm(ctx, w->x, D, w->lnp_g, w->lnp_b, w->xa, xa_out, D, M, D, 1e-5f, stream));
+  // cross-attention K/V for every decoder layer (head-major, not transposed: decode streams rows)
+  for (int l = 0; l < d.n_text_layer; l++) {
+    const DecLayer& L = w->dec[l];
+    memset(&p, 0, sizeof(p));
+    p.A = w->xa; p.lda = D; p.W = L.Wckv; p.ldw = D; p.M = M; p.N = 2 * D; p.K = D; p.bias = L.bckv;
+    p.hk = L.crossK; p.hv = L.crossV; p.d_model = D; p.n_head = H; p.S = S; p.Spad = w->Spad; p.v_transposed = 0;
+    p.first_block = 1;
+    TRY(ccx_launch_gemm(ctx, EPI_HEADS, p, stream));
+  }
+  return CCX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int cross_split(int B, int H) {
+  int ns = ccx_cdiv(512, B * H);
+  if (ns < 1) ns = 1;
+  if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
+  return ns;
+}
+
+// One decoder step for B sequences on `stream`.  logits go to `logits` with row stride ld.
+int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, hipStream_t stream) {
+  ccx_ctx* ctx = w->ctx;
+  const ccx_whisper_dims& d = w->d;
+  const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
+  const float scale_log2e = 0.125f * 1.4426950408889634f;
+  const int ns = cross_split(B, H);
+  TRY(ccx_launch_dec_embed(ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, D, stream));
+  for (int l = 0; l < d.n_text_layer; l++) {
+    const DecLayer& L = w->dec[l];
+    DecLinearParams lp;
+    // LN + QKV, k/v appended to the self cache at pos[b]
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = 3 * D; lp.K = D; lp.W = L.Wqkv; lp.ldw = D; lp.bias = L.bqkv;
+    lp.x = w->dx; lp.ln_g = L.ln1_g; lp.ln_b = L.ln1_b; lp.eps = 1e-5f;
+    lp.out = w->dq; lp.ldo = D; lp.cache_k = L.selfK; lp.cache_v = L.selfV; lp.cache_T = Tc; lp.pos = w->pos;
+    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_SELF_QKV, lp, stream));
+    DecAttnParams ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.q = w->dq; ap.k = L.selfK; ap.v = L.selfV; ap.H = H; ap.kv_T = Tc; ap.pos = w->pos; ap.scale_log2e = scale_log2e;
+    ap.out_bf16 = w->dattn;
+    TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wo; lp.ldw = D; lp.bias = L.bo; lp.act = w->dattn; lp.lda = D;
+    lp.out = w->dx; lp.ldo = D;
+    TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32_ACCUM, lp, stream));
+    // cross attention
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wcq; lp.ldw = D; lp.bias = L.bcq;
+    lp.x = w->dx; lp.ln_g = L.lnc_g; lp.ln_b = L.lnc_b; lp.eps = 1e-5f; lp.out = w->dq; lp.ldo = D;
+    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_F32, lp, stream));
+    memset(&ap, 0, sizeof(ap));
+    ap.q = w->dq; ap.k = L.crossK; ap.v = L.crossV; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
+    ap.scale_log2e = scale_log2e; ap.part_o = w->part_o; ap.part_ml = w->part_ml;
+    TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wco; lp.ldw = D; lp.bias = L.bco;
+    lp.part_o = w->part_o; lp.part_ml = w->part_ml; lp.nsplit = ns; lp.out = w->dx; lp.ldo = D;
+    TRY(ccx_launch_dec_linear(ctx, ACT_COMBINE, DEPI_F32_ACCUM, lp, stream));
+    // MLP
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = F; lp.K = D; lp.W = L.W1; lp.ldw = D; lp.bias = L.b1;
+    lp.x = w->dx; lp.ln_g = L.ln2_g; lp.ln_b = L.ln2_b; lp.eps = 1e-5f; lp.out = w->dffn; lp.ldo = F;
+    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_BF16_GELU, lp, stream));
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = D; lp.K = F; lp.W = L.W2; lp.ldw = F; lp.bias = L.b2; lp.act = w->dffn; lp.lda = F;
+    lp.out = w->dx; lp.ldo = D;
+    TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32_ACCUM, lp, stream));
+  }
+  // final LN + logits against the tied embedding
+  {
+    DecLinearParams lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = d.n_vocab; lp.K = D; lp.W = w->tok_emb_bf16; lp.ldw = D; lp.bias = nullptr;
+    lp.x = w->dx; lp.ln_g = w->lnd_g; lp.ln_b = w->lnd_b; lp.eps = 1e-5f; lp.out = logits; lp.ldo = ld;
+    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_F32, lp, stream));
+  }
+  if (select) {
+    DecSelectParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.logits = logits; sp.ld_logits = ld; sp.n_vocab = d.n_vocab; sp.state = w->state; sp.prompt = w->prompt;
+    sp.max_prompt = max_prompt; sp.cur_tok = w->cur_tok; sp.pos = w->pos; sp.gen = w->gen; sp.sample_len = sample_len;
+    sp.n_done = w->n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
+    sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
+    sp.max_initial_ts = w->rules.max_initial_timestamp_index;
+    TRY(ccx_launch_dec_select(ctx, sp, B, stream));
+  }
+  return CCX_OK;
+}
+
+int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
+                        hipStream_t stream) {
+  std::vector<DecSeqState> st(B);
+  std::vector<int> tok(B), ps(B, 0);
+  for (int b = 0; b < B; b++) {
+    memset(&st[b], 0, sizeof(DecSeqState));
+    st[b].prompt_len = prompt_lens[b];
+    st[b].last_tok = -1; st[b].pen_tok = -1; st[b].last_ts_tok = -1;
+    tok[b] = prompt_ids[(size_t)b * max_prompt];
+  }
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->state, st.data(), B * sizeof(DecSeqState), hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->cur_tok, tok.data(), B * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->pos, ps.data(), B * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->prompt, prompt_ids, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, 16, stream));
+  CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host vectors go out of scope
+  return CCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int T, float* logits_dev, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  ccx_ctx* ctx = w->ctx;
+  CCX_REQUIRE(ctx, w->finalized && w->rules_set, "whisper: not finalized or rules not set");
+  CCX_REQUIRE(ctx, tokens && logits_dev && B >= 1 && B <= w->max_batch && T >= 1 && T <= w->d.n_text_ctx, "decoder_logits: bad arguments");
+  for (long i = 0; i < (long)B * T; i++)
+    CCX_REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < w->d.n_vocab, "decoder_logits: token id %d out of range", tokens[i]);
+  std::vector<int32_t> lens(B, T + 1);  // never leaves the prompt phase: every step feeds tokens[b][pos]
+  // prompt buffer rows are `T` wide here
+  TRY(upload_decode_state(w, tokens, lens.data(), T, B, stream));
+  const long V = w->d.n_vocab;
+  for (int t = 0; t < T; t++) {
+    // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it
+    TRY(dec_step(w, B, logits_dev + (long)t * V, (long)T * V, t + 1 < T, 1, T, stream));
+  }
+  return CCX_OK;
+}
+
+int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
+                              int sample_len, int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
+                              float* no_speech_prob_out, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  ccx_ctx* ctx = w->ctx;
+  CCX_REQUIRE(ctx, w->finalized && w->rules_set, "whisper: not finalized or rules not set");
+  CCX_REQUIRE(ctx, prompt_ids && prompt_lens && tokens_out && B >= 1 && B <= w->max_batch, "decode_greedy: bad arguments");
+  CCX_REQUIRE(ctx, sample_len >= 1 && sample_len <= w->sample_cap && max_prompt >= 1 && max_prompt <= w->max_prompt_cap, "decode_greedy: sample_len/max_prompt out of range");
+  int max_pl = 0;
+  for (int b = 0; b < B; b++) {
+    CCX_REQUIRE(ctx, prompt_lens[b] >= 1 && prompt_lens[b] <= max_prompt, "decode_greedy: prompt_lens[%d]=%d out of range", b, prompt_lens[b]);
+    CCX_REQUIRE(ctx, prompt_lens[b] + sample_len - 1 <= w->d.n_text_ctx, "decode_greedy: prompt %d + sample_len %d exceeds n_text_ctx", prompt_lens[b], sample_len);
+    for (int i = 0; i < prompt_lens[b]; i++) {
+      const int t = prompt_ids[(size_t)b * max_prompt + i];
+      CCX_REQUIRE(ctx, t >= 0 && t < w->d.n_vocab, "decode_greedy: prompt token %d out of range", t);
+    }
+    if (prompt_lens[b] > max_pl) max_pl = prompt_lens[b];
+  }
+  TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, stream));
+  const int total_steps = max_pl - 1 + sample_len;
+  const bool use_graph = getenv("CCX_NO_GRAPH") == nullptr;
+  const long ld = w->Vpad;
+  // graphs are specific to (B, sample_len, max_prompt): key on all three
+  const int key = B * 1000003 + sample_len * 1009 + max_prompt;
+  int step = 0;
+  // first step runs eagerly (also performs one-time kernel attribute setup outside of capture)
+  TRY(dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream));
+  step = 1;
+  hipGraphExec_t exec = nullptr;
+  if (use_graph && total_steps > 1) {
+    auto it = w->graphs.find(key);
+    if (it != w->graphs.end()) exec = it->second;
+    else {
+      hipGraph_t graph = nullptr;
+      CCX_HIP(ctx, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      int rc = dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream);
+      hipError_t e = hipStreamEndCapture(stream, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (e != hipSuccess) return ccx_fail(ctx, CCX_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e != hipSuccess) return ccx_fail(ctx, CCX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+      w->graphs[key] = exec;
+    }
+  }
+  int n_done_host = 0;
+  while (step < total_steps) {
+    const int chunk = (total_steps - step < 16) ? total_steps - step : 16;
+    for (int i = 0; i < chunk; i++) {
+      if (exec) CCX_HIP(ctx, hipGraphLaunch(exec, stream));
+      else TRY(dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream));
+    }
+    step += chunk;
+    CCX_HIP(ctx, hipMemcpyAsync(&n_done_host, w->n_done, 4, hipMemcpyDeviceToHost, stream));
+    CCX_HIP(ctx, hipStreamSynchronize(stream));
+    if (n_done_host >= B) break;
+  }
+  std::vector<DecSeqState> st(B);
+  std::vector<int> gen((size_t)B * sample_len);
+  CCX_HIP(ctx, hipMemcpyAsync(st.data(), w->state, B * sizeof(DecSeqState), hipMemcpyDeviceToHost, stream));
+  CCX_HIP(ctx, hipMemcpyAsync(gen.data(), w->gen, gen.size() * 4, hipMemcpyDeviceToHost, stream));
+  CCX_HIP(ctx, hipStreamSynchronize(stream));
+  for (int b = 0; b < B; b++) {
+    const int ng = st[b].n_gen < sample_len ? st[b].n_gen : sample_len;
+    // not done after the step budget: treat everything sampled as text (no eot was produced)
+    const int ntok = st[b].done ? st[b].n_tokens : ng;
+    for (int i = 0; i < sample_len; i++) tokens_out[(size_t)b * sample_len + i] = (i < ntok) ? gen[(size_t)b * sample_len + i] : w->rules.eot;
+    if (n_tokens_out) n_tokens_out[b] = ntok;
+    if (sum_logprob_out) sum_logprob_out[b] = st[b].sum_logprob;
+    if (no_speech_prob_out) no_speech_prob_out[b] = st[b].no_speech_prob;
+  }
+  return CCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+/* ccx.h -- C ABI of libccx, the MI355X-native (gfx950) compute library behind
+ * ClearConverse's overlapped-speech transcription path.
+ *
+ * The reference has NO FFI for this path: EnhancedAudioProcessor calls duck-typed Python model
+ * objects (reference back/api.py:657-797 creates them, back/api.py:1298-1549 drives them).  Each
+ * entry point below states which of those Python calls it replaces; clearconverse_amd/_lib.py is
+ * the ctypes binding and INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: every function returns 0 (CCX_OK) or a non-zero status and stores a message
+ * retrievable with ccx_last_error(ctx).  All `*_dev` pointers are HIP device pointers owned by the
+ * caller (torch allocates them); `stream` is a hipStream_t passed as void*.  The library owns only
+ * weights, caches, workspaces and graphs inside its handles; it has no global state and starts no
+ * threads, so it is safe to initialise after fork (reference back/api.py:2045-2049 forks per task).
+ */
+#ifndef CCX_H
+#define CCX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCX_DTYPE_F32 0
+#define CCX_DTYPE_BF16 1
+#define CCX_DTYPE_F16 2
+
+typedef struct ccx_ctx ccx_ctx;
+typedef struct ccx_whisper ccx_whisper;
+
+const char* ccx_version(void);
+int ccx_ctx_create(int device, ccx_ctx** out);
+void ccx_ctx_destroy(ccx_ctx* ctx);
+/* Last error text of this context ("" if none). ctx == NULL returns the text of the last failed
+ * ccx_ctx_create on this thread. */
+const char* ccx_last_error(const ccx_ctx* ctx);
+
+/* ---- primitive operators (exposed so tests/ can check each kernel against oracle/) ------------ */
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias) with a fused epilogue; bf16 inputs, fp32 accumulate (MFMA).
+ * epi: 0 bf16 out | 1 bf16 gelu | 2 f32 out = acc+bias+resid | 3 f32 out | 5 bf16 relu.
+ * Replaces the torch.nn.Linear / Conv1d-as-GEMM calls inside whisper / speechbrain / pyannote
+ * modules that the reference triggers at back/api.py:1077, 869, 1286. */
+int ccx_gemm_bf16(ccx_ctx* ctx, int epi, const void* A_dev, int64_t lda, const void* W_dev, int64_t ldw,
+                  const float* bias_dev, void* out_dev, int64_t ldo, const float* resid_dev, int64_t ldr,
+                  int M, int N, int K, void* stream);
+
+/* LayerNorm over the last dim with fp32 statistics; writes bf16 and/or fp32 (either may be NULL). */
+int ccx_layernorm(ccx_ctx* ctx, const float* x_dev, const float* gamma_dev, const float* beta_dev,
+                  void* out_bf16_dev, float* out_f32_dev, int M, int D, float eps, void* stream);
+
+/* Non-causal attention, head_dim 64 (Whisper encoder).  q,k: [B*H, Spad, 64] bf16 with rows >= S
+ * zero; vt: [B*H, 64, Spad] bf16; o: [B*S, H*64] bf16.  Softmax scale 1/8 (= 64^-0.25 on q and k). */
+int ccx_enc_attention(ccx_ctx* ctx, const void* q_dev, const void* k_dev, const void* vt_dev, void* o_dev,
+                      int B, int H, int S, int Spad, void* stream);
+
+/* ---- Whisper (replaces self.whisper_model, reference back/api.py:665-703; calls at
+ *      back/api.py:1286-1292, 1432-1438, 1474-1480) ---------------------------------------------- */
+
+typedef struct {
+  int n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} ccx_whisper_dims;
+
+/* Token-id constants of the tokenizer the checkpoint was trained with (openai-whisper
+ * tokenizer.py; for *.en models sot=50257, eot=50256, ... see clearconverse_amd/tokenizer.py). */
+typedef struct {
+  int eot, sot, sot_prev, no_speech, no_timestamps, timestamp_begin, blank; /* blank = id of " " */
+  int max_initial_timestamp_index;  /* 50 = 1.0 s; < 0 disables the rule */
+  int n_suppress;
+  const int* suppress;              /* host array, copied */
+} ccx_decode_rules;
+
+int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch, ccx_whisper** out);
+void ccx_whisper_destroy(ccx_whisper* w);
+/* Register one tensor by its openai-whisper state_dict name (the key layout of the reference's
+ * fine-tune overlay, back/api.py:671-692), plus "mel_filters" [n_mels, 201].  data may be a host
+ * or a device pointer.  Unknown names are an error. */
+int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, int dtype, int ndim,
+                           const int64_t* shape);
+/* Checks every tensor is present, builds the fused/bf16 device layouts, uploads. */
+int ccx_whisper_finalize(ccx_whisper* w);
+int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* rules);
+
+/* Log-mel of B clips (whisper.audio.log_mel_spectrogram + pad_or_trim to 3000 frames).
+ * audio_dev: [B, stride] f32; n_samples / seek_frames: host int arrays (seek may be NULL = 0).
+ * Fills the model's conv-stem input; if mel_out_dev != NULL also writes [B, n_mels, 3000] f32. */
+int ccx_whisper_logmel(ccx_whisper* w, const float* audio_dev, int64_t stride, const int* n_samples,
+                       const int* seek_frames, int B, float* mel_out_dev, void* stream);
+/* Alternative input: take a ready [B, n_mels, 3000] f32 mel (BASELINE config 2 "mel [8,80,3000]"). */
+int ccx_whisper_set_mel(ccx_whisper* w, const float* mel_dev, int B, void* stream);
+/* AudioEncoder.forward for the B staged windows + per-layer cross-attention K/V projection.
+ * xa_out_dev (optional): [B, n_audio_ctx, n_audio_state] f32 copy of the encoder output. */
+int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out_dev, void* stream);
+
+/* Teacher-forced decoder pass for parity tests: tokens [B, T] (host int32) -> logits
+ * [B, T, n_vocab] f32 on device.  Uses the same step kernels as greedy decoding. */
+int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int T, float* logits_dev,
+                               void* stream);
+
+/* Greedy (temperature 0) DecodingTask.run for the B encoded windows.
+ * prompt_ids: host [B, max_prompt] initial tokens (sot_prev + prompt + sot), prompt_lens: [B].
+ * Outputs (host): tokens [B, sample_len] sampled ids (eot-padded), n_tokens [B] count before eot,
+ * sum_logprob [B], no_speech_prob [B]. */
+int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens,
+                              int max_prompt, int B, int sample_len, int32_t* tokens_out,
+                              int32_t* n_tokens_out, float* sum_logprob_out, float* no_speech_prob_out,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCX_H */

@@ -1,0 +1,103 @@
+"""-m gpu: each hand-written HIP kernel, called through the C ABI, against a plain fp32 torch
+reference of the same op computed on the CPU from the SAME bf16-rounded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _rel(a, b):
+    a = a.double().flatten(); b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1500, 768, 768), (12000, 2304, 768), (77, 384, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 5])
+def test_gemm_bf16(ccx_ctx, M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + epi)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = A.float() @ W.float().T + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == 5:
+        ref = torch.relu(ref)
+    elif epi == 2:
+        ref = ref + resid
+    Ad, Wd, bd, rd = A.cuda(), W.cuda(), bias.cuda(), resid.cuda()
+    out_dtype = torch.bfloat16 if epi in (0, 1, 5) else torch.float32
+    out = torch.full((M, N), float("nan"), dtype=out_dtype, device="cuda")
+    lib = ccx_ctx.lib
+    rc = lib.ccx_gemm_bf16(ccx_ctx.handle, epi, Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), out.data_ptr(), N,
+                           rd.data_ptr() if epi == 2 else None, N, M, N, K, _stream())
+    ccx_ctx.check(rc, "gemm")
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    tol = 6e-3 if out_dtype == torch.bfloat16 else 2e-5   # bf16 output rounding: 2^-9 relative per element
+    assert _rel(got, ref) < tol, _rel(got, ref)
+    # element-wise: identical inputs, fp32 accumulate -> only summation order / output rounding differ
+    atol = 0.05 if out_dtype == torch.bfloat16 else 2e-3
+    assert float((got - ref).abs().max()) < atol
+
+
+def test_gemm_rejects_bad_k(ccx_ctx):
+    a = torch.zeros(128, 96, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 96, dtype=torch.bfloat16, device="cuda")
+    o = torch.zeros(128, 128, dtype=torch.bfloat16, device="cuda")
+    rc = ccx_ctx.lib.ccx_gemm_bf16(ccx_ctx.handle, 0, a.data_ptr(), 96, w.data_ptr(), 96, None, o.data_ptr(), 128, None, 0,
+                                   128, 128, 96, _stream())
+    assert rc != 0 and b"multiple of 64" in ccx_ctx.lib.ccx_last_error(ccx_ctx.handle)
+
+
+@pytest.mark.parametrize("M,D", [(5, 128), (1500, 768), (12000, 768), (33, 1024)])
+def test_layernorm(ccx_ctx, M, D):
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 3 + 0.5
+    gamma = 1 + 0.1 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+    ob = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    of = torch.empty(M, D, dtype=torch.float32, device="cuda")
+    rc = ccx_ctx.lib.ccx_layernorm(ccx_ctx.handle, x.cuda().data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(),
+                                   ob.data_ptr(), of.data_ptr(), M, D, 1e-5, _stream())
+    ccx_ctx.check(rc, "layernorm")
+    torch.cuda.synchronize()
+    assert float((of.cpu() - ref).abs().max()) < 2e-5
+    assert float((ob.float().cpu() - ref).abs().max()) < 0.03
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 200), (1, 12, 1500)])
+def test_enc_attention(ccx_ctx, B, H, S):
+    g = torch.Generator().manual_seed(B * 100 + H * 10 + S)
+    Spad = (S + 127) // 128 * 128
+    q = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16)
+    # a few large scores so the online-softmax rescale path is exercised at a late key tile
+    k[:, :, S - 3] *= 6.0
+    sc = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    ref = torch.softmax(sc, dim=-1) @ v.float()          # [B,H,S,64]
+    ref = ref.permute(0, 2, 1, 3).reshape(B * S, H * 64)
+    qp = torch.zeros(B, H, Spad, 64, dtype=torch.bfloat16); qp[:, :, :S] = q
+    kp = torch.zeros(B, H, Spad, 64, dtype=torch.bfloat16); kp[:, :, :S] = k
+    vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16); vt[:, :, :, :S] = v.transpose(-1, -2)
+    o = torch.full((B * S, H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = ccx_ctx.lib.ccx_enc_attention(ccx_ctx.handle, qp.cuda().data_ptr(), kp.cuda().data_ptr(), vt.cuda().data_ptr(),
+                                       o.data_ptr(), B, H, S, Spad, _stream())
+    ccx_ctx.check(rc, "enc_attention")
+    torch.cuda.synchronize()
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    assert float((got - ref).abs().max()) < 0.06
