@@ -101,8 +101,11 @@ struct ccx_whisper {
   int *cur_tok = nullptr, *pos = nullptr, *prompt = nullptr, *gen = nullptr, *n_done = nullptr;
   DecSeqState* state = nullptr;
   int max_prompt_cap = 0, sample_cap = 0;
-  // graph cache
+  // graph cache; decode runs on an internal stream when the caller hands over the legacy null
+  // stream (stream capture is illegal there)
   std::map<int, hipGraphExec_t> graphs;
+  hipStream_t own_stream = nullptr;
+  hipEvent_t own_event = nullptr;
 };
 
 namespace {
@@ -242,6 +245,8 @@ int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch
 void ccx_whisper_destroy(ccx_whisper* w) {
   if (!w) return;
   for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
+  if (w->own_stream) hipStreamDestroy(w->own_stream);
+  if (w->own_event) hipEventDestroy(w->own_event);
   for (void* p : w->allocs) hipFree(p);
   delete w;
 }
@@ -424,6 +429,8 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   w->sample_cap = d.n_text_ctx;
   TRY(dev_alloc(w, &w->prompt, (size_t)B * w->max_prompt_cap, true));
   TRY(dev_alloc(w, &w->gen, (size_t)B * w->sample_cap, true));
+  CCX_HIP(w->ctx, hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
+  CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->own_event, hipEventDisableTiming));
   w->finalized = true;
   return CCX_OK;
 }
@@ -667,6 +674,12 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
   ccx_ctx* ctx = w->ctx;
   CCX_REQUIRE(ctx, w->finalized && w->rules_set, "whisper: not finalized or rules not set");
   CCX_REQUIRE(ctx, prompt_ids && prompt_lens && tokens_out && B >= 1 && B <= w->max_batch, "decode_greedy: bad arguments");
+  if (stream == nullptr) {
+    // order after everything already queued on the caller's (null) stream, then run on our own
+    CCX_HIP(ctx, hipEventRecord(w->own_event, nullptr));
+    CCX_HIP(ctx, hipStreamWaitEvent(w->own_stream, w->own_event, 0));
+    stream = w->own_stream;
+  }
   CCX_REQUIRE(ctx, sample_len >= 1 && sample_len <= w->sample_cap && max_prompt >= 1 && max_prompt <= w->max_prompt_cap, "decode_greedy: sample_len/max_prompt out of range");
   int max_pl = 0;
   for (int b = 0; b < B; b++) {

@@ -68,7 +68,8 @@ def test_layernorm(ccx_ctx, M, D):
     ref = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
     ob = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
     of = torch.empty(M, D, dtype=torch.float32, device="cuda")
-    rc = ccx_ctx.lib.ccx_layernorm(ccx_ctx.handle, x.cuda().data_ptr(), gamma.cuda().data_ptr(), beta.cuda().data_ptr(),
+    xd, gd, bd = x.cuda(), gamma.cuda(), beta.cuda()   # keep the device copies alive across the call
+    rc = ccx_ctx.lib.ccx_layernorm(ccx_ctx.handle, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
                                    ob.data_ptr(), of.data_ptr(), M, D, 1e-5, _stream())
     ccx_ctx.check(rc, "layernorm")
     torch.cuda.synchronize()
@@ -92,7 +93,8 @@ def test_enc_attention(ccx_ctx, B, H, S):
     kp = torch.zeros(B, H, Spad, 64, dtype=torch.bfloat16); kp[:, :, :S] = k
     vt = torch.zeros(B, H, 64, Spad, dtype=torch.bfloat16); vt[:, :, :, :S] = v.transpose(-1, -2)
     o = torch.full((B * S, H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
-    rc = ccx_ctx.lib.ccx_enc_attention(ccx_ctx.handle, qp.cuda().data_ptr(), kp.cuda().data_ptr(), vt.cuda().data_ptr(),
+    qd, kd, vd = qp.cuda(), kp.cuda(), vt.cuda()
+    rc = ccx_ctx.lib.ccx_enc_attention(ccx_ctx.handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
                                        o.data_ptr(), B, H, S, Spad, _stream())
     ccx_ctx.check(rc, "enc_attention")
     torch.cuda.synchronize()
