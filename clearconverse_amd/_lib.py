@@ -43,6 +43,9 @@ PROTOTYPES = {
     "ccx_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "ccx_ctx_destroy": (None, [_vp]),
     "ccx_last_error": (C.c_char_p, [_vp]),
+    "ccx_prof_enable": (_i, [_vp, _i]),
+    "ccx_prof_count": (_i, [_vp]),
+    "ccx_prof_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _fp]),
     "ccx_gemm_bf16": (_i, [_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "ccx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ccx_enc_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -99,6 +102,19 @@ class Context:
     def check(self, rc: int, what: str = ""):
         if rc != 0:
             raise CcxError(f"{what or 'ccx call'} failed ({rc}): {self.lib.ccx_last_error(self.handle).decode()}")
+
+    def prof_enable(self, on: bool = True):
+        self.check(self.lib.ccx_prof_enable(self.handle, 1 if on else 0), "ccx_prof_enable")
+
+    def prof_records(self):
+        """[(kernel name, algorithmic flops, algorithmic bytes, ms)] for every recorded launch."""
+        out = []
+        buf = C.create_string_buffer(64)
+        fl, by, ms = C.c_double(), C.c_double(), C.c_float()
+        for i in range(self.lib.ccx_prof_count(self.handle)):
+            self.check(self.lib.ccx_prof_get(self.handle, i, buf, 64, C.byref(fl), C.byref(by), C.byref(ms)), "ccx_prof_get")
+            out.append((buf.value.decode(), fl.value, by.value, ms.value))
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

@@ -44,7 +44,39 @@ int ccx_ctx_create(int device, ccx_ctx** out) {
   return CCX_OK;
 }
 
-void ccx_ctx_destroy(ccx_ctx* ctx) { delete ctx; }
+static void prof_clear(ccx_ctx* ctx) {
+  for (auto& r : ctx->prof) { hipEventDestroy(r.start); hipEventDestroy(r.stop); }
+  ctx->prof.clear();
+}
+
+void ccx_ctx_destroy(ccx_ctx* ctx) {
+  if (!ctx) return;
+  prof_clear(ctx);
+  delete ctx;
+}
+
+int ccx_prof_enable(ccx_ctx* ctx, int on) {
+  if (!ctx) return CCX_ERR_ARG;
+  prof_clear(ctx);
+  ctx->prof_on = on != 0;
+  return CCX_OK;
+}
+
+int ccx_prof_count(ccx_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
+
+int ccx_prof_get(ccx_ctx* ctx, int i, char* name_out, int name_cap, double* flops, double* bytes, float* ms) {
+  if (!ctx) return CCX_ERR_ARG;
+  CCX_REQUIRE(ctx, i >= 0 && i < (int)ctx->prof.size() && name_out && name_cap > 1, "ccx_prof_get: bad index %d", i);
+  const ccx_prof_rec& r = ctx->prof[i];
+  CCX_HIP(ctx, hipEventSynchronize(r.stop));
+  float t = 0.f;
+  CCX_HIP(ctx, hipEventElapsedTime(&t, r.start, r.stop));
+  snprintf(name_out, name_cap, "%s", r.name);
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  if (ms) *ms = t;
+  return CCX_OK;
+}
 
 const char* ccx_last_error(const ccx_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 

@@ -176,7 +176,11 @@ int ccx_launch_enc_attention(ccx_ctx* ctx, const bf16_t* Q, const bf16_t* K, con
   CCX_REQUIRE(ctx, Spad % 64 == 0 && Spad >= S, "enc_attention: Spad=%d must be a multiple of 64 and >= S=%d", Spad, S);
   const float scale_log2e = 0.125f * 1.4426950408889634f;  // head_dim 64: (64^-0.25)^2 = 1/8
   dim3 grid(ccx_cdiv(S, 128), B * n_head);
-  hipLaunchKernelGGL(enc_attention_kernel, grid, dim3(256), 0, stream, Q, K, Vt, O, S, Spad, n_head, scale_log2e);
+  {
+    const double bh = (double)B * n_head;
+    ccx_prof_scope ps(ctx, stream, "enc_attention_kernel", 4.0 * bh * S * (double)S * 64, 2.0 * bh * S * 64 * 4);
+    hipLaunchKernelGGL(enc_attention_kernel, grid, dim3(256), 0, stream, Q, K, Vt, O, S, Spad, n_head, scale_log2e);
+  }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }

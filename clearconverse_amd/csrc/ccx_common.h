@@ -24,9 +24,36 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// One timed launch (HIP events on the launch stream) -- filled only while profiling is enabled.
+struct ccx_prof_rec {
+  const char* name;
+  double flops, bytes;  // algorithmic work of this launch
+  hipEvent_t start, stop;
+};
+
 struct ccx_ctx {
   int device;
   std::string last_error;
+  bool prof_on = false;
+  std::vector<ccx_prof_rec> prof;
+};
+
+// RAII: records start/stop events around a kernel launch when ctx->prof_on (never inside a
+// stream capture: the caller passes capturing=true there).
+struct ccx_prof_scope {
+  ccx_ctx* ctx; hipStream_t stream; bool active; size_t idx;
+  ccx_prof_scope(ccx_ctx* c, hipStream_t s, const char* name, double flops, double bytes) : ctx(c), stream(s), active(false), idx(0) {
+    if (!c || !c->prof_on) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    ccx_prof_rec r{name, flops, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+    hipEventRecord(r.start, s);
+    c->prof.push_back(r);
+    idx = c->prof.size() - 1;
+    active = true;
+  }
+  ~ccx_prof_scope() { if (active) hipEventRecord(ctx->prof[idx].stop, stream); }
 };
 
 // Set ctx error text and return the code (host side).
@@ -72,15 +99,55 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-__device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions on the DPP path (VALU speed; __shfl_xor lowers to ds_bpermute, which
+// costs an LDS round trip per step and dominated the latency of the small decode kernels) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+#define CCX_DPP_QUAD_XOR1 0xB1    // quad_perm [1,0,3,2]
+#define CCX_DPP_QUAD_XOR2 0x4E    // quad_perm [2,3,0,1]
+#define CCX_DPP_HALF_MIRROR 0x141 // lane i <-> 7-i inside each 8-lane half row
+#define CCX_DPP_ROW_MIRROR 0x140  // lane i <-> 15-i inside each 16-lane row
+
+// value held by lane (l ^ 16) / (l ^ 32): gfx950 v_permlane16_swap / v_permlane32_swap
+__device__ __forceinline__ float lane_xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+  return __uint_as_float(((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = [lo,lo], r[1] = [hi,hi]
+  return __uint_as_float(((threadIdx.x >> 5) & 1) ? r[0] : r[1]);
+}
+
+// Sum over aligned groups of 8 lanes; every lane of the group gets the sum.
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_mov<CCX_DPP_QUAD_XOR1>(v);
+  v += dpp_mov<CCX_DPP_QUAD_XOR2>(v);
+  v += dpp_mov<CCX_DPP_HALF_MIRROR>(v);
   return v;
 }
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+  v = group8_sum(v);
+  v += dpp_mov<CCX_DPP_ROW_MIRROR>(v);  // 16-lane row sums
+  const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+  const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+  const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+  const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+  return (a + b) + (c + d);
+}
 __device__ __forceinline__ float wave_reduce_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<CCX_DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dpp_mov<CCX_DPP_QUAD_XOR2>(v));
+  v = fmaxf(v, dpp_mov<CCX_DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<CCX_DPP_ROW_MIRROR>(v));
+  const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+  const float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+  const float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+  const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 __host__ __device__ static inline int ccx_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -3,23 +3,29 @@
 #include "ccx_common.h"
 
 enum { ACT_LN = 0, ACT_BF16 = 1, ACT_COMBINE = 2 };
-enum { DEPI_BF16 = 0, DEPI_BF16_GELU = 1, DEPI_F32_ACCUM = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4 };
+enum { DEPI_BF16_GELU = 1, DEPI_PARTIAL = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4 };
 
 struct DecLinearParams {
   int M, N, K;
   const bf16_t* W; long ldw;      // [N][K]
   const float* bias;              // [N] or null
   // activation sources
-  const float* x;                 // ACT_LN: [M][K] f32 residual stream
+  const float* x;                 // ACT_LN: [M][K] f32 residual stream (before the pending partials)
+  const float* pend; int pend_n; long pend_stride;  // pending split-K partials [pend_n][M][K] folded into x
+  float* x_out;                   // ACT_LN: if non-null, block (0,*,0) writes x + sum(pend) here (must differ from x)
   const float* ln_g; const float* ln_b; float eps;
   const bf16_t* act; long lda;    // ACT_BF16: [M][K]
   const float* part_o; const float* part_ml; int nsplit;  // ACT_COMBINE: [M][H][nsplit][64], [M][H][nsplit][2]
-  // outputs
+  // outputs (DEPI_PARTIAL: out[z][m][n] with stride pend_stride between the grid.z slices)
   void* out; long ldo;
   // DEPI_SELF_QKV: q -> out (f32 [M][K]), k/v -> caches [M][H][cache_T][64] at pos[m]
   bf16_t* cache_k; bf16_t* cache_v; int cache_T; const int* pos;
 };
 int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams& p, hipStream_t stream);
+// number of grid.z K-slices ccx_launch_dec_linear will use (= number of partial slabs written)
+int ccx_dec_linear_ksplit(int K, int epi);
+int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
+                              const float* b, bf16_t* out, int M, int K, float eps, hipStream_t stream);
 
 struct DecAttnParams {
   const float* q;       // [B][H][64] f32
@@ -48,8 +54,10 @@ struct DecSelectParams {
   int* cur_tok; int* pos;
   int* gen; int sample_len;
   int* n_done;
-  const unsigned char* suppress_mask;  // [n_vocab]
+  const unsigned char* suppress_mask;  // [n_vocab rounded up to 4]
   int eot, blank, no_speech, timestamp_begin, max_initial_ts;
+  // next-step embedding written by the select kernel: x[b] = tok_emb[next] + pos_emb[pos]
+  const float* tok_emb; const float* pos_emb; float* x; int D;
 };
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,

@@ -38,7 +38,20 @@ __global__ void dec_embed_kernel(const float* __restrict__ tok_emb, const float*
 // ------------------------------------------------------------------------------------------
 // Skinny linear
 // ------------------------------------------------------------------------------------------
-template <int MT, int NT, int ACT, int EPI>
+// Every kernel of the decode chain is latency-bound (a 768x768 bf16 matrix is 4.6 KB per CU, and a
+// slot of a dependent graph chain costs ~1.6 us even when empty -- tools/microbench_chain.hip), so
+// the structure minimises instructions and dependent round trips on the one critical path:
+//  1. each wave issues ALL weight loads of its K slice first (<= KMAX x NT 16-byte non-temporal
+//     loads per lane: each weight byte is read once per step);
+//  2. the activation prologue runs under that flight: LayerNorm of the residual rows (live rows
+//     only, two at a time), or the split-KV attention combine, or nothing (bf16 activations are
+//     loaded as fragments, also all up front);
+//  3. MFMAs run out of registers; the 4 waves (K split) reduce through LDS.
+// Residual adds are DEFERRED: out-proj / cross-out / FFN2 write split-K partial sums (DEPI_PARTIAL,
+// grid.z = K split, so 4.7 MB matrices spread over 192 blocks instead of 48) and the NEXT
+// LayerNorm prologue folds them in (x_eff = x_in + sum partials), block (0,*,0) writing x_eff to
+// the other residual buffer (ping-pong: no block may see a half-updated stream).
+template <int MT, int NT, int KMAX, int ACT, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MROWS = 16 * MT;
@@ -49,133 +62,199 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   const int K = p.K;
   const int lds_ld = K + 8;  // bf16 elements per LDS activation row (ACT_LN / ACT_COMBINE only)
   bf16_t* act_s = (bf16_t*)smem;
-  // reduction scratch aliases the activation image when ACT_BF16 (no image) else sits after it
   float* red = (float*)(smem + ((ACT == ACT_BF16) ? 0 : ccx_align((size_t)MROWS * lds_ld * 2, 16)));
 
-  // ---------------- activation staging ----------------
-  if (ACT == ACT_LN) {
-    // one wave per row: LayerNorm(x[m]) -> bf16 LDS row (K == d_model <= 1024)
-    for (int r = wave; r < MROWS; r += 4) {
-      const int m = m0 + r;
-      const int nv = K >> 2;
-      float4 v[4];
-      float s = 0.f;
-      const float4* xr = (const float4*)(p.x + (long)(m < p.M ? m : 0) * K);
+  const int l15 = lane & 15, h4 = lane >> 4;
+  // K range of this block (grid.z split), then of this wave
+  const int ksteps = K >> 5;
+  const int per_z = (ksteps + gridDim.z - 1) / gridDim.z;
+  const int kz0 = blockIdx.z * per_z;
+  const int kz1 = (kz0 + per_z < ksteps) ? kz0 + per_z : ksteps;
+  const int per_w = (kz1 - kz0 + 3) >> 2;
+  const int ks0 = kz0 + wave * per_w;
+  int nks = kz1 - ks0;
+  nks = nks < 0 ? 0 : (nks > per_w ? per_w : nks);
+
+  // ---------------- 1. weight (and bf16 activation) prefetch ----------------
+  // W is stored fragment-packed (whisper.hip pack_mfma_rows): tile (n/16, k/32) holds the 64 lanes'
+  // 16-byte A fragments back to back, so one wave load is 1 KB contiguous and successive k-steps
+  // are successive KBs.  Rows >= N are zero padding inside the packed image.
+  bf16x8 wf[NT][KMAX];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int idx = lane + 64 * i;
-        if (idx < nv) { v[i] = xr[idx]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+  for (int i = 0; i < NT; i++) {
+    const long tile = (long)(blockIdx.x * NT + i) * ksteps + ks0;
+    const bf16_t* wr = p.W + (tile * 64 + lane) * 8;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      const int kk = k < nks ? k : 0;  // clamp instead of branching: keeps the loads back to back
+      wf[i][k] = __builtin_nontemporal_load((const bf16x8*)(wr + 512 * kk));
+    }
+  }
+  bf16x8 af[MT][KMAX];
+  if (ACT == ACT_BF16) {
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+      int m = m0 + 16 * j + l15;
+      m = m < p.M ? m : p.M - 1;  // rows >= M compute garbage that is never stored
+      const bf16_t* ar = p.act + (long)m * p.lda + 8 * h4 + 32 * ks0;
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        const int kk = k < nks ? k : 0;
+        af[j][k] = *(const bf16x8*)(ar + 32 * kk);
       }
-      const float mean = wave_reduce_sum(s) / (float)K;
-      float q = 0.f;
+    }
+  }
+
+  // ---------------- 2. activation staging ----------------
+  if (ACT == ACT_LN) {
+    // x_eff = x + sum of pending split-K partials; LayerNorm(x_eff) -> bf16 LDS rows (K <= 1024).
+    // A wave owns live rows wave, wave+4, ... and handles two of them per pass.
+    const int nv = K >> 2;
+    int live = p.M - m0;
+    live = live > MROWS ? MROWS : live;
+    const bool writer = (blockIdx.x == 0 && blockIdx.z == 0 && p.x_out != nullptr);
+    float4 g[4], bb[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int idx = lane + 64 * i;
-        if (idx < nv) {
-          const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-          q += a * a + b * b + c * c + d * d;
+    for (int i = 0; i < 4; i++) {
+      const int idx = lane + 64 * i;
+      const int ic = idx < nv ? idx : 0;
+      g[i] = ((const float4*)p.ln_g)[ic];
+      bb[i] = ((const float4*)p.ln_b)[ic];
+    }
+    for (int r0 = wave; r0 < live; r0 += 8) {
+      float4 v[2][4];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int r = r0 + 4 * u;
+        ok[u] = r < live;
+        const long row = (long)(m0 + (ok[u] ? r : r0)) * K;
+        const float4* xr = (const float4*)(p.x + row);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int idx = lane + 64 * i;
+          const int ic = idx < nv ? idx : 0;
+          float4 a = xr[ic];
+          float4 q[4];
+#pragma unroll
+          for (int s = 0; s < 4; s++)  // all slab loads issued together (clamped index, masked add)
+            q[s] = ((const float4*)(p.pend + (long)(s < p.pend_n ? s : 0) * p.pend_stride + row))[ic];
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            const float wgt = s < p.pend_n ? 1.f : 0.f;
+            a.x += wgt * q[s].x; a.y += wgt * q[s].y; a.z += wgt * q[s].z; a.w += wgt * q[s].w;
+          }
+          if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
+          v[u][i] = a;
         }
       }
-      const float rstd = rsqrtf(wave_reduce_sum(q) / (float)K + p.eps);
+      float mean[2], rstd[2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int idx = lane + 64 * i;
-        if (idx < nv) {
-          const float4 g = ((const float4*)p.ln_g)[idx], bb = ((const float4*)p.ln_b)[idx];
-          uint2 o;
-          if (m < p.M) {
-            o.x = pack_bf16x2((v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y);
-            o.y = pack_bf16x2((v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w);
-          } else {
-            o.x = 0; o.y = 0;
+      for (int u = 0; u < 2; u++) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) sm += (v[u][i].x + v[u][i].y) + (v[u][i].z + v[u][i].w);
+        mean[u] = wave_reduce_sum(sm) / (float)K;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float a = v[u][i].x - mean[u], b = v[u][i].y - mean[u], c = v[u][i].z - mean[u], d = v[u][i].w - mean[u];
+          const float t = a * a + b * b + c * c + d * d;
+          sq += (lane + 64 * i < nv) ? t : 0.f;
+        }
+        rstd[u] = rsqrtf(wave_reduce_sum(sq) / (float)K + p.eps);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!ok[u]) continue;
+        const int r = r0 + 4 * u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int idx = lane + 64 * i;
+          if (idx < nv) {
+            uint2 o;
+            o.x = pack_bf16x2((v[u][i].x - mean[u]) * rstd[u] * g[i].x + bb[i].x, (v[u][i].y - mean[u]) * rstd[u] * g[i].y + bb[i].y);
+            o.y = pack_bf16x2((v[u][i].z - mean[u]) * rstd[u] * g[i].z + bb[i].z, (v[u][i].w - mean[u]) * rstd[u] * g[i].w + bb[i].w);
+            *(uint2*)(act_s + (long)r * lds_ld + 4 * idx) = o;
+            if (writer) ((float4*)(p.x_out + (long)(m0 + r) * K))[idx] = v[u][i];
           }
-          *(uint2*)(act_s + (long)r * lds_ld + 4 * idx) = o;
         }
       }
     }
+    // dead rows of the 16-row MFMA tile: zeros
+    for (int r = live + wave; r < MROWS; r += 4)
+      for (int idx = lane; idx < (K >> 2); idx += 64) *(uint2*)(act_s + (long)r * lds_ld + 4 * idx) = make_uint2(0, 0);
     __syncthreads();
   } else if (ACT == ACT_COMBINE) {
-    // combine split-KV attention partials: act[m][h*64+d] = sum_s w_s o_s[d] / sum_s w_s l_s
+    // combine split-KV attention partials: act[m][h*64+d] = sum_s w_s o_s[d] / sum_s w_s l_s.
+    // One thread per (row, head, 8-wide d chunk); all partial loads (nsplit <= 8) issued up front.
     const int H = K >> 6;
-    for (int e = tid; e < MROWS * H * 8; e += 256) {  // one thread per (row, head, 8-wide d chunk)
+    for (int e = tid; e < MROWS * H * 8; e += 256) {
       const int c = e & 7, h = (e >> 3) % H, r = e / (8 * H);
       const int m = m0 + r;
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) o[j] = 0.f;
+      uint4 pk = make_uint4(0, 0, 0, 0);
       if (m < p.M) {
-        const float* ml = p.part_ml + ((long)(m * H + h) * p.nsplit) * 2;
+        const float2* ml = (const float2*)(p.part_ml + ((long)(m * H + h) * p.nsplit) * 2);
+        const float* ob = p.part_o + ((long)(m * H + h) * p.nsplit) * 64 + 8 * c;
+        float2 mlv[8];
+        float4 oa[8], oc[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const int sc = s < p.nsplit ? s : 0;
+          mlv[s] = ml[sc];
+          oa[s] = *(const float4*)(ob + sc * 64);
+          oc[s] = *(const float4*)(ob + sc * 64 + 4);
+          if (s >= p.nsplit) mlv[s] = make_float2(-1e30f, 0.f);
+        }
         float mx = -1e30f;
-        for (int s = 0; s < p.nsplit; s++) mx = fmaxf(mx, ml[2 * s]);
-        float den = 0.f;
-        for (int s = 0; s < p.nsplit; s++) {
-          const float w = __builtin_amdgcn_exp2f(ml[2 * s] - mx);
-          den += w * ml[2 * s + 1];
-          const float4* op = (const float4*)(p.part_o + ((long)(m * H + h) * p.nsplit + s) * 64 + 8 * c);
-          const float4 a = op[0], b4 = op[1];
-          o[0] += w * a.x; o[1] += w * a.y; o[2] += w * a.z; o[3] += w * a.w;
-          o[4] += w * b4.x; o[5] += w * b4.y; o[6] += w * b4.z; o[7] += w * b4.w;
+#pragma unroll
+        for (int s = 0; s < 8; s++) mx = fmaxf(mx, mlv[s].x);
+        float den = 0.f, o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const float w = (s < p.nsplit) ? __builtin_amdgcn_exp2f(mlv[s].x - mx) : 0.f;
+          den += w * mlv[s].y;
+          o[0] += w * oa[s].x; o[1] += w * oa[s].y; o[2] += w * oa[s].z; o[3] += w * oa[s].w;
+          o[4] += w * oc[s].x; o[5] += w * oc[s].y; o[6] += w * oc[s].z; o[7] += w * oc[s].w;
         }
         const float inv = 1.0f / den;
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] *= inv;
+        pk.x = pack_bf16x2(o[0] * inv, o[1] * inv); pk.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+        pk.z = pack_bf16x2(o[4] * inv, o[5] * inv); pk.w = pack_bf16x2(o[6] * inv, o[7] * inv);
       }
-      uint4 pk;
-      pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]);
-      pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
       *(uint4*)(act_s + (long)r * lds_ld + h * 64 + 8 * c) = pk;
     }
     __syncthreads();
   }
 
-  // ---------------- main loop: this wave's K slice ----------------
+  // ---------------- 3. MFMAs out of the prefetched registers ----------------
   f32x4 acc[NT][MT];
 #pragma unroll
   for (int i = 0; i < NT; i++)
 #pragma unroll
     for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int l15 = lane & 15, h4 = lane >> 4;
-  const int ksteps = K >> 5;
-  const int ks_per_wave = (ksteps + 3) >> 2;
-  const int ks0 = wave * ks_per_wave;
-  const int ks1 = (ks0 + ks_per_wave < ksteps) ? ks0 + ks_per_wave : ksteps;
-
-  const bf16_t* wrow[NT];
 #pragma unroll
-  for (int i = 0; i < NT; i++) {
-    int n = n0 + 16 * i + l15;
-    n = n < p.N ? n : p.N - 1;
-    wrow[i] = p.W + (long)n * p.ldw + 8 * h4;
-  }
-  const bf16_t* arow[MT];
+  for (int k = 0; k < KMAX; k++) {
+    if (k < nks) {
+      if (ACT != ACT_BF16) {
 #pragma unroll
-  for (int j = 0; j < MT; j++) {
-    if (ACT == ACT_BF16) {
-      int m = m0 + 16 * j + l15;
-      m = m < p.M ? m : p.M - 1;  // rows >= M compute garbage that is never stored
-      arow[j] = p.act + (long)m * p.lda + 8 * h4;
-    } else {
-      arow[j] = act_s + (long)(16 * j + l15) * lds_ld + 8 * h4;
+        for (int j = 0; j < MT; j++)
+          af[j][k] = *(const bf16x8*)(act_s + (long)(16 * j + l15) * lds_ld + 8 * h4 + 32 * (ks0 + k));
+      }
+#pragma unroll
+      for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][k], af[j][k], acc[i][j], 0, 0, 0);
     }
   }
 
-#pragma unroll 4
-  for (int ks = ks0; ks < ks1; ks++) {
-    bf16x8 wf[NT], af[MT];
-#pragma unroll
-    for (int i = 0; i < NT; i++) wf[i] = __builtin_nontemporal_load((const bf16x8*)(wrow[i] + 32 * ks));
-#pragma unroll
-    for (int j = 0; j < MT; j++) af[j] = *(const bf16x8*)(arow[j] + 32 * ks);
-#pragma unroll
-    for (int i = 0; i < NT; i++)
-#pragma unroll
-      for (int j = 0; j < MT; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-  }
-
-  // ---------------- cross-wave reduction through LDS ----------------
-  __syncthreads();  // everyone is done reading the activation image (red may alias nothing, but keep order)
+  // ---------------- 4. cross-wave reduction through LDS + epilogue ----------------
+  __syncthreads();  // everyone is done reading the activation image
 #pragma unroll
   for (int i = 0; i < NT; i++)
 #pragma unroll
@@ -191,13 +270,11 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; w++) v += red[(((w * NT + i) * MT + j) * 64 + ln) * 4 + rg];
-    if (p.bias) v += p.bias[n];
-    if (EPI == DEPI_BF16) {
-      ((bf16_t*)p.out)[(long)m * p.ldo + n] = f32_to_bf16(v);
-    } else if (EPI == DEPI_BF16_GELU) {
+    if (p.bias && blockIdx.z == 0) v += p.bias[n];
+    if (EPI == DEPI_BF16_GELU) {
       ((bf16_t*)p.out)[(long)m * p.ldo + n] = f32_to_bf16(gelu_erf(v));
-    } else if (EPI == DEPI_F32_ACCUM) {
-      ((float*)p.out)[(long)m * p.ldo + n] += v;
+    } else if (EPI == DEPI_PARTIAL) {
+      ((float*)p.out)[(long)blockIdx.z * p.pend_stride + (long)m * p.ldo + n] = v;
     } else if (EPI == DEPI_F32) {
       ((float*)p.out)[(long)m * p.ldo + n] = v;
     } else if (EPI == DEPI_SELF_QKV) {
@@ -216,53 +293,120 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   }
 }
 
-template <int MT, int NT, int ACT, int EPI>
-static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, hipStream_t stream) {
+// Stand-alone residual resolve + LayerNorm -> bf16 (input of the logits GEMV): one wave per row.
+__global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __restrict__ x, const float* __restrict__ pend,
+                                                             int pend_n, long pend_stride, const float* __restrict__ g,
+                                                             const float* __restrict__ b, bf16_t* __restrict__ out, int M,
+                                                             int K, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int nv = K >> 2;
+  float4 v[4];
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    const int ic = idx < nv ? idx : 0;
+    float4 a = ((const float4*)(x + (long)m * K))[ic];
+    float4 q[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) q[s] = ((const float4*)(pend + (long)(s < pend_n ? s : 0) * pend_stride + (long)m * K))[ic];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const float wgt = s < pend_n ? 1.f : 0.f;
+      a.x += wgt * q[s].x; a.y += wgt * q[s].y; a.z += wgt * q[s].z; a.w += wgt * q[s].w;
+    }
+    if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = a;
+    sm += (a.x + a.y) + (a.z + a.w);
+  }
+  const float mean = wave_reduce_sum(sm) / (float)K;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+    sq += (lane + 64 * i < nv) ? (a * a + c * c + d * d + e * e) : 0.f;
+  }
+  const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)K + eps);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    if (idx < nv) {
+      const float4 gg = ((const float4*)g)[idx], bb = ((const float4*)b)[idx];
+      uint2 o;
+      o.x = pack_bf16x2((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y);
+      o.y = pack_bf16x2((v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+      ((uint2*)(out + (long)m * K))[idx] = o;
+    }
+  }
+}
+
+int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
+                              const float* b, bf16_t* out, int M, int K, float eps, hipStream_t stream) {
+  CCX_REQUIRE(ctx, K % 4 == 0 && K <= 1024, "dec_resolve_ln: K=%d unsupported", K);
+  hipLaunchKernelGGL(dec_resolve_ln_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, pend, pend_n, pend_stride, g, b,
+                     out, M, K, eps);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+template <int MT, int NT, int KMAX, int ACT, int EPI>
+static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
   const int MROWS = 16 * MT, BN = 16 * NT;
   size_t act_bytes = (ACT == ACT_BF16) ? 0 : ccx_align((size_t)MROWS * (p.K + 8) * 2, 16);
   size_t red_bytes = (size_t)4 * NT * MT * 64 * 4 * 4;
   size_t lds = act_bytes + red_bytes;
   CCX_REQUIRE(ctx, lds <= 160 * 1024, "dec_linear: LDS %zu too large", lds);
+  CCX_REQUIRE(ctx, ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), 4) <= KMAX, "dec_linear: K=%d / split %d exceeds the prefetch depth %d", p.K, ksplit, KMAX);
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && lds > attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_linear_kernel<MT, NT, ACT, EPI>,
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = 160 * 1024;
   }
-  dim3 grid(ccx_cdiv(p.N, BN), ccx_cdiv(p.M, MROWS));
-  hipLaunchKernelGGL((dec_linear_kernel<MT, NT, ACT, EPI>), grid, dim3(256), lds, stream, p);
+  dim3 grid(ccx_cdiv(p.N, BN), ccx_cdiv(p.M, MROWS), ksplit);
+  {
+    // weight-streaming GEMV: algorithmic bytes = the weight matrix once (+ small activations)
+    ccx_prof_scope ps(ctx, stream, "dec_linear_kernel", 2.0 * p.M * (double)p.N * p.K,
+                      2.0 * (double)p.N * p.K + 2.0 * p.M * ((double)p.K + p.N));
+    hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI>), grid, dim3(256), lds, stream, p);
+  }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }
 
-template <int ACT, int EPI>
-static int launch_dec_linear_mt(ccx_ctx* ctx, const DecLinearParams& p, int nt, hipStream_t stream) {
+template <int NT, int ACT, int EPI>
+static int launch_dec_linear_mt(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
   const int M = p.M;
-  if (nt == 4) {
-    if (M <= 16) return launch_dec_linear_inst<1, 4, ACT, EPI>(ctx, p, stream);
-    if (M <= 32) return launch_dec_linear_inst<2, 4, ACT, EPI>(ctx, p, stream);
-    return launch_dec_linear_inst<4, 4, ACT, EPI>(ctx, p, stream);
-  }
-  if (M <= 16) return launch_dec_linear_inst<1, 1, ACT, EPI>(ctx, p, stream);
-  if (M <= 32) return launch_dec_linear_inst<2, 1, ACT, EPI>(ctx, p, stream);
-  return launch_dec_linear_inst<4, 1, ACT, EPI>(ctx, p, stream);
+  if (M <= 16) return launch_dec_linear_inst<1, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
+  if (M <= 32) return launch_dec_linear_inst<2, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
+  return launch_dec_linear_inst<4, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
+}
+
+int ccx_dec_linear_ksplit(int K, int epi) {
+  // prefetch depth is 8 k-steps (256 elements) per wave, 4 waves per block
+  int ks = ccx_cdiv(K, 1024);
+  if (epi != DEPI_PARTIAL) return ks;  // only partial outputs can be split across blocks
+  return ks < 1 ? 1 : ks;
 }
 
 int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, p.M > 0 && p.N > 0 && p.K > 0 && p.K % 32 == 0, "dec_linear: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   CCX_REQUIRE(ctx, act == ACT_BF16 || p.K <= 1024, "dec_linear: LN/combine activation needs K <= 1024");
-  CCX_REQUIRE(ctx, p.ldw % 8 == 0, "dec_linear: ldw must be a multiple of 8");
-  // wide-N layers use 64-row weight panels per block, narrow ones 16 to spread over more CUs
-  const int nt = (p.N >= 8192) ? 4 : 1;
-#define CASE(A, E) \
-  if (act == A && epi == E) return launch_dec_linear_mt<A, E>(ctx, p, nt, stream);
-  CASE(ACT_LN, DEPI_SELF_QKV)
-  CASE(ACT_LN, DEPI_F32)
-  CASE(ACT_LN, DEPI_BF16_GELU)
-  CASE(ACT_BF16, DEPI_F32_ACCUM)
-  CASE(ACT_BF16, DEPI_F32)
-  CASE(ACT_COMBINE, DEPI_F32_ACCUM)
-#undef CASE
+  CCX_REQUIRE(ctx, p.pend_n >= 0 && p.pend_n <= 4, "dec_linear: at most 4 pending slabs");
+  const int ksplit = ccx_dec_linear_ksplit(p.K, epi);
+  CCX_REQUIRE(ctx, epi == DEPI_PARTIAL || ksplit == 1, "dec_linear: K=%d needs a split-K (partial) epilogue", p.K);
+  CCX_REQUIRE(ctx, epi != DEPI_PARTIAL || p.pend_stride >= (long)p.M * p.ldo, "dec_linear: pend_stride too small");
+  // wide-N layers (logits) use 64-row weight panels per block, narrow ones 16 to spread over more CUs
+  const bool wide = p.N >= 8192;
+  if (act == ACT_BF16 && epi == DEPI_F32 && wide) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
+  if (act == ACT_LN && epi == DEPI_SELF_QKV) return launch_dec_linear_mt<1, ACT_LN, DEPI_SELF_QKV>(ctx, p, 1, stream);
+  if (act == ACT_LN && epi == DEPI_F32) return launch_dec_linear_mt<1, ACT_LN, DEPI_F32>(ctx, p, 1, stream);
+  if (act == ACT_LN && epi == DEPI_BF16_GELU) return launch_dec_linear_mt<1, ACT_LN, DEPI_BF16_GELU>(ctx, p, 1, stream);
+  if (act == ACT_COMBINE && epi == DEPI_PARTIAL) return launch_dec_linear_mt<1, ACT_COMBINE, DEPI_PARTIAL>(ctx, p, ksplit, stream);
+  if (act == ACT_BF16 && epi == DEPI_PARTIAL) return launch_dec_linear_mt<1, ACT_BF16, DEPI_PARTIAL>(ctx, p, ksplit, stream);
+  if (act == ACT_BF16 && epi == DEPI_F32) return launch_dec_linear_mt<1, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
   return ccx_fail(ctx, CCX_ERR_ARG, "dec_linear: unsupported act=%d epi=%d", act, epi);
 }
 
@@ -281,6 +425,9 @@ __device__ __forceinline__ void soft_merge(SoftState& a, float bm, float bl, con
   a.m = mx;
 }
 
+// A wave instruction covers 8 keys x 128 B (lane group g = key, lane&7 = 16-byte d chunk).  A wave
+// owns 64-key chunks and issues all 16 K/V loads of a chunk before touching the data, so one
+// HBM round trip covers the chunk.
 template <bool FINAL>
 __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
   __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
@@ -289,66 +436,90 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const int g = lane >> 3, c = lane & 7;
   const int T = p.pos ? (p.pos[b] + 1) : p.T;
-  // this block's key range
   const int per = (T + gridDim.y - 1) / gridDim.y;
   const int kbeg = split * per;
   const int kend = (kbeg + per < T) ? kbeg + per : T;
 
+  const bf16_t* Kb = p.k + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Vb = p.v + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+
+  float sm = -1e30f, sl = 0.f, so[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) so[j] = 0.f;
   float q[8];
   {
     const float4* qp = (const float4*)(p.q + ((long)b * p.H + h) * 64 + 8 * c);
     const float4 a = qp[0], d = qp[1];
     q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = d.x; q[5] = d.y; q[6] = d.z; q[7] = d.w;
-#pragma unroll
-    for (int j = 0; j < 8; j++) q[j] *= p.scale_log2e;
   }
-  const bf16_t* Kb = p.k + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
-  const bf16_t* Vb = p.v + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
 
-  SoftState st;
-  st.m = -1e30f; st.l = 0.f;
+  for (int base = kbeg + wave * 64; base < kend; base += 256) {
+    bf16x8 kf[8], vf[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) st.o[j] = 0.f;
-
-  // each wave instruction covers 8 keys (one per lane group g); waves interleave in units of 8 keys
-  for (int k0 = kbeg + wave * 8; k0 < kend; k0 += 32) {
-    const int key = k0 + g;
-    const bool ok = key < kend;
-    const int kk = ok ? key : (kend - 1);
-    const bf16x8 kv = *(const bf16x8*)(Kb + (long)kk * 64);
-    const bf16x8 vv = *(const bf16x8*)(Vb + (long)kk * 64);
-    float s = 0.f;
+    for (int it = 0; it < 8; it++) {
+      int key = base + it * 8 + g;
+      key = key < kend ? key : kend - 1;
+      kf[it] = *(const bf16x8*)(Kb + (long)key * 64);
+      vf[it] = *(const bf16x8*)(Vb + (long)key * 64);
+    }
+    float s[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s = fmaf(q[j], bf16_to_f32((bf16_t)kv[j]), s);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (!ok) s = -INFINITY;
-    const float mn = fmaxf(st.m, s);
-    const float al = __builtin_amdgcn_exp2f(st.m - mn);
-    const float pe = __builtin_amdgcn_exp2f(s - mn);
-    st.l = st.l * al + pe;
+    for (int it = 0; it < 8; it++) {
+      float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; j++) st.o[j] = st.o[j] * al + pe * bf16_to_f32((bf16_t)vv[j]);
-    st.m = mn;
+      for (int j = 0; j < 8; j++) a = fmaf(q[j], bf16_to_f32((bf16_t)kf[it][j]), a);
+      a = group8_sum(a) * p.scale_log2e;
+      s[it] = (base + it * 8 + g < kend) ? a : -INFINITY;
+    }
+    float mn = sm;
+#pragma unroll
+    for (int it = 0; it < 8; it++) mn = fmaxf(mn, s[it]);
+    const float al = __builtin_amdgcn_exp2f(sm - mn);
+    sl *= al;
+#pragma unroll
+    for (int j = 0; j < 8; j++) so[j] *= al;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const float pe = __builtin_amdgcn_exp2f(s[it] - mn);
+      sl += pe;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[j] = fmaf(pe, bf16_to_f32((bf16_t)vf[it][j]), so[j]);
+    }
+    sm = mn;
   }
-  // merge the 8 lane groups (lanes with equal c): xor 8, 16, 32
+  // merge the 8 lane groups (lanes with equal c) in registers: xor 8 via DPP row_ror:8, xor 16 /
+  // xor 32 via v_permlane16_swap / v_permlane32_swap (VALU speed, no LDS round trips)
+  {
+    auto merge_with = [&](float om, float ol, const float (&oo)[8]) {
+      const float mx = fmaxf(sm, om);
+      const float wa = __builtin_amdgcn_exp2f(sm - mx), wb = __builtin_amdgcn_exp2f(om - mx);
+      sl = sl * wa + ol * wb;
 #pragma unroll
-  for (int off = 8; off < 64; off <<= 1) {
-    const float bm = __shfl_xor(st.m, off, 64), bl = __shfl_xor(st.l, off, 64);
-    float bo[8];
+      for (int j = 0; j < 8; j++) so[j] = so[j] * wa + oo[j] * wb;
+      sm = mx;
+    };
+    float om, ol, oo[8];
+    om = dpp_mov<0x128>(sm); ol = dpp_mov<0x128>(sl);
 #pragma unroll
-    for (int j = 0; j < 8; j++) bo[j] = __shfl_xor(st.o[j], off, 64);
-    soft_merge(st, bm, bl, bo);
+    for (int j = 0; j < 8; j++) oo[j] = dpp_mov<0x128>(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor16(sm); ol = lane_xor16(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor16(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor32(sm); ol = lane_xor32(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor32(so[j]);
+    merge_with(om, ol, oo);
   }
   if (g == 0) {
-    sm_m[wave][c] = st.m; sm_l[wave][c] = st.l;
+    sm_m[wave][c] = sm; sm_l[wave][c] = sl;
 #pragma unroll
-    for (int j = 0; j < 8; j++) sm_o[wave][c][j] = st.o[j];
+    for (int j = 0; j < 8; j++) sm_o[wave][c][j] = so[j];
   }
   __syncthreads();
   if (tid < 64) {
-    // thread -> d = tid; merge 4 waves
+    // thread -> d = tid = 8*cc + j; merge the 4 waves
     const int cc = tid >> 3, j = tid & 7;
     float mx = fmaxf(fmaxf(sm_m[0][cc], sm_m[1][cc]), fmaxf(sm_m[2][cc], sm_m[3][cc]));
     float l = 0.f, o = 0.f;
@@ -361,9 +532,9 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
     if (FINAL) {
       p.out_bf16[((long)b * p.H + h) * 64 + tid] = f32_to_bf16(o / l);
     } else {
-      const long base = ((long)b * p.H + h) * gridDim.y + split;
-      p.part_o[base * 64 + tid] = o;
-      if (tid == 0) { p.part_ml[base * 2] = mx; p.part_ml[base * 2 + 1] = l; }
+      const long pbase = ((long)b * p.H + h) * gridDim.y + split;
+      p.part_o[pbase * 64 + tid] = o;
+      if (tid == 0) { p.part_ml[pbase * 2] = mx; p.part_ml[pbase * 2 + 1] = l; }
     }
   }
 }
@@ -373,8 +544,13 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
   CCX_REQUIRE(ctx, B > 0 && p.H > 0 && nsplit >= 1, "dec_attention: bad shape");
   CCX_REQUIRE(ctx, !final_out || nsplit == 1, "dec_attention: final output needs nsplit == 1");
   dim3 grid(B * p.H, nsplit);
-  if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), 0, stream, p);
+  {
+    const double keys = p.pos ? 0.0 : (double)p.T;  // self-attention length varies per row: not priced
+    ccx_prof_scope ps(ctx, stream, final_out ? "dec_attention_self" : "dec_attention_cross", 4.0 * B * p.H * keys * 64,
+                      (double)B * p.H * keys * 64 * 2 * 2);
+    if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), 0, stream, p);
+  }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }
@@ -403,27 +579,47 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
   return r;
 }
 
+// One block (1024 threads) per sequence.  The whole logit row (<= 53248 values) is loaded ONCE
+// into registers (13 float4 per thread, all loads issued before any use) together with the
+// suppress mask; every reduction then runs out of registers.  The kernel also writes the input
+// embedding of the NEXT step (token + position), so the step chain needs no separate embed launch.
+#define SEL_V4 13
 __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   __shared__ float sh[16];
   __shared__ float sh_v[16];
   __shared__ int sh_i[16];
+  __shared__ int sh_next[2];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int V = p.n_vocab;
   const float* lg = p.logits + (long)b * p.ld_logits;
   DecSeqState s = p.state[b];  // every thread reads the same struct ...
-  __syncthreads();             // ... before thread 0 may overwrite it in an early-exit branch
+  __syncthreads();             // ... before thread 0 may overwrite it below
+
+  auto embed_next = [&](int tok, int pos) {
+    // x[b] = tok_emb[tok] + pos_emb[pos]  (TextDecoder.forward input of the next step)
+    const float4* te = (const float4*)(p.tok_emb + (long)tok * p.D);
+    const float4* pe = (const float4*)(p.pos_emb + (long)pos * p.D);
+    float4* xo = (float4*)(p.x + (long)b * p.D);
+    for (int i = tid; i < p.D / 4; i += blockDim.x) {
+      const float4 a = te[i], c = pe[i];
+      xo[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+  };
 
   // ---- prompt phase: feed the next prompt token, nothing is sampled ----
   if (s.pos < s.prompt_len - 1) {
+    const int np = s.pos + 1;
+    const int tok = p.prompt[(long)b * p.max_prompt + np];
+    embed_next(tok, np);
     if (tid == 0) {
-      s.pos += 1;
-      p.cur_tok[b] = p.prompt[(long)b * p.max_prompt + s.pos];
-      p.pos[b] = s.pos;
+      s.pos = np;
+      p.cur_tok[b] = tok;
+      p.pos[b] = np;
       p.state[b] = s;
     }
     return;
   }
-  if (s.done) {  // finished rows keep emitting eot; nothing else changes
+  if (s.done) {  // finished rows keep emitting eot; the model input stays as it is
     if (tid == 0 && s.n_gen < p.sample_len) {
       p.gen[(long)b * p.sample_len + s.n_gen] = p.eot;
       s.n_gen += 1;
@@ -432,59 +628,77 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
     return;
   }
 
+  // ---- load the row + mask once ----
+  float val[SEL_V4 * 4];
+  unsigned long long sup = 0;  // bit i: element i of this thread is suppressed / out of range
+#pragma unroll
+  for (int i = 0; i < SEL_V4; i++) {
+    const int v0 = tid * 4 + i * 4096;
+    if (v0 + 3 < V) {
+      const float4 f = *(const float4*)(lg + v0);
+      const uchar4 m = *(const uchar4*)(p.suppress_mask + v0);
+      val[4 * i] = f.x; val[4 * i + 1] = f.y; val[4 * i + 2] = f.z; val[4 * i + 3] = f.w;
+      sup |= ((unsigned long long)((m.x ? 1 : 0) | (m.y ? 2 : 0) | (m.z ? 4 : 0) | (m.w ? 8 : 0))) << (4 * i);
+    } else {  // n_vocab % 4 == 0 (checked on the host): a float4 is either fully inside or fully outside
+      val[4 * i] = val[4 * i + 1] = val[4 * i + 2] = val[4 * i + 3] = -INFINITY;
+      sup |= 0xFull << (4 * i);
+    }
+  }
   const int i_gen = s.n_gen;
   const int tsb = p.timestamp_begin;
+
   // ---- no-speech probability from the raw logits at the SOT position (first sampling step) ----
   if (i_gen == 0) {
     float mx = -INFINITY;
-    for (int v = tid; v < V; v += blockDim.x) mx = fmaxf(mx, lg[v]);
+#pragma unroll
+    for (int i = 0; i < SEL_V4 * 4; i++) mx = fmaxf(mx, val[i]);
     mx = block_reduce_max(mx, sh);
     float sum = 0.f;
-    for (int v = tid; v < V; v += blockDim.x) sum += expf(lg[v] - mx);
+#pragma unroll
+    for (int i = 0; i < SEL_V4 * 4; i++) sum += __builtin_amdgcn_exp2f((val[i] - mx) * 1.4426950408889634f);  // -inf -> 0
     sum = block_reduce_sum(sum, sh);
     if (tid == 0) s.no_speech_prob = expf(lg[p.no_speech] - mx) / sum;
   }
 
-  // ---- timestamp-rule state (ApplyTimestampRules) ----
+  // ---- timestamp-rule state (ApplyTimestampRules) folded into two allowed id ranges ----
+  // text ids   [t_lo, tsb):  empty on the first step (must start with a timestamp); only >= eot after
+  //                          "text, timestamp" (a timestamp must be paired or followed by eot)
+  // timestamps [s_lo, s_hi): >= the last timestamp (+1 unless it is still unpaired); empty after a
+  //                          closed pair "timestamp, timestamp"; <= max_initial_timestamp on the first step
+  // SuppressBlank only matters on the first step, where every text id is banned anyway.
   const bool last_ts = i_gen >= 1 && s.last_tok >= tsb;
   const bool pen_ts = i_gen < 2 || s.pen_tok >= tsb;
-  int ts_floor = tsb;  // timestamps in [tsb, ts_floor) are banned
-  if (s.last_ts_tok >= 0) ts_floor = (last_ts && !pen_ts) ? s.last_ts_tok : s.last_ts_tok + 1;
+  int s_lo = tsb;
+  if (s.last_ts_tok >= 0) s_lo = (last_ts && !pen_ts) ? s.last_ts_tok : s.last_ts_tok + 1;
+  int s_hi = V;
+  if (i_gen == 0 && p.max_initial_ts >= 0) s_hi = tsb + p.max_initial_ts + 1;
+  if (last_ts && pen_ts) s_hi = s_lo;
+  const int t_lo = (i_gen == 0) ? tsb : ((last_ts && !pen_ts) ? p.eot : 0);
 
-  auto masked = [&](int v) -> bool {
-    if (p.suppress_mask[v]) return true;                      // SuppressTokens + <|notimestamps|>
-    if (i_gen == 0 && (v == p.blank || v == p.eot)) return true;  // SuppressBlank
-    if (last_ts) {
-      if (pen_ts) { if (v >= tsb) return true; }
-      else { if (v < p.eot) return true; }
-    }
-    if (v >= tsb && v < ts_floor) return true;
-    if (i_gen == 0) {
-      if (v < tsb) return true;
-      if (p.max_initial_ts >= 0 && v > tsb + p.max_initial_ts) return true;
-    }
-    return false;
-  };
-
-  // pass 1: maxima (text / timestamp) over the filtered logits
+  // pass 1 (registers): apply the filters in place (-inf) and take text / timestamp maxima
   float mx_text = -INFINITY, mx_ts = -INFINITY;
   int am_text = 0x7fffffff, am_ts = 0x7fffffff;
-  for (int v = tid; v < V; v += blockDim.x) {
-    if (masked(v)) continue;
-    const float x = lg[v];
-    if (v < tsb) { if (x > mx_text) { mx_text = x; am_text = v; } }
-    else { if (x > mx_ts) { mx_ts = x; am_ts = v; } }
+#pragma unroll
+  for (int i = 0; i < SEL_V4 * 4; i++) {
+    const int v = tid * 4 + (i >> 2) * 4096 + (i & 3);
+    const bool is_text = v < tsb;
+    const bool allowed = !((sup >> i) & 1) && (is_text ? (v >= t_lo) : (v >= s_lo && v < s_hi));
+    const float x = allowed ? val[i] : -INFINITY;
+    val[i] = x;
+    const bool bt_ = is_text && x > mx_text, bs_ = !is_text && x > mx_ts;
+    mx_text = bt_ ? x : mx_text; am_text = bt_ ? v : am_text;
+    mx_ts = bs_ ? x : mx_ts; am_ts = bs_ ? v : am_ts;
   }
   // block argmax (ties -> lowest index, as torch.argmax on CPU)
-  auto block_argmax = [&](float val, int idx, float& oval, int& oidx) {
+  auto block_argmax = [&](float v_, int idx, float& oval, int& oidx) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(val, o, 64);
+      const float ov = __shfl_xor(v_, o, 64);
       const int oi = __shfl_xor(idx, o, 64);
-      if (ov > val || (ov == val && oi < idx)) { val = ov; idx = oi; }
+      if (ov > v_ || (ov == v_ && oi < idx)) { v_ = ov; idx = oi; }
     }
     __syncthreads();
-    if ((tid & 63) == 0) { sh_v[tid >> 6] = val; sh_i[tid >> 6] = idx; }
+    if ((tid & 63) == 0) { sh_v[tid >> 6] = v_; sh_i[tid >> 6] = idx; }
     __syncthreads();
     oval = sh_v[0]; oidx = sh_i[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); w++)
@@ -495,12 +709,14 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   block_argmax(mx_ts, am_ts, bs, is);
   const float mx_all = fmaxf(bt, bs);
 
-  // pass 2: sum exp over text and over timestamps (relative to mx_all)
+  // pass 2 (registers): sum exp over text and over timestamps (relative to mx_all)
   float se_text = 0.f, se_ts = 0.f;
-  for (int v = tid; v < V; v += blockDim.x) {
-    if (masked(v)) continue;
-    const float e = expf(lg[v] - mx_all);
-    if (v < tsb) se_text += e; else se_ts += e;
+#pragma unroll
+  for (int i = 0; i < SEL_V4 * 4; i++) {
+    const int v = tid * 4 + (i >> 2) * 4096 + (i & 3);
+    const float e = __builtin_amdgcn_exp2f((val[i] - mx_all) * 1.4426950408889634f);  // banned entries are -inf -> 0
+    se_text += (v < tsb) ? e : 0.f;
+    se_ts += (v < tsb) ? 0.f : e;
   }
   se_text = block_reduce_sum(se_text, sh);
   se_ts = block_reduce_sum(se_ts, sh);
@@ -524,6 +740,7 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
     s.pen_tok = s.last_tok;
     s.last_tok = next;
     if (next >= tsb) s.last_ts_tok = next;
+    int cont = 0;
     if (next == p.eot) {
       s.done = 1;
       s.n_tokens = i_gen;  // tokens before the first eot
@@ -536,9 +753,14 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
       s.pos += 1;
       p.cur_tok[b] = next;
       p.pos[b] = s.pos;
+      cont = 1;
     }
     p.state[b] = s;
+    sh_next[0] = cont ? next : -1;
+    sh_next[1] = s.pos;
   }
+  __syncthreads();
+  if (sh_next[0] >= 0) embed_next(sh_next[0], sh_next[1]);
 }
 
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,

@@ -245,7 +245,13 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+  {
+    // algorithmic work: 2*M*N*K flops; bytes = A + W read once + output written once
+    const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;
+    ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * p.K,
+                      2.0 * ((double)p.M * p.K + (double)p.N * p.K) + obytes * p.M * (double)p.N);
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+  }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }

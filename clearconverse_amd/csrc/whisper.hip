@@ -68,6 +68,8 @@ struct ccx_whisper {
   bool finalized = false;
   std::map<std::string, HostTensor> staged;
   std::vector<void*> allocs;
+  char* arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
 
   // derived sizes
   int Spad = 0;    // padded audio context (multiple of 128)
@@ -96,8 +98,8 @@ struct ccx_whisper {
          *ffn = nullptr, *xa = nullptr;
   float* x = nullptr;
   // workspaces (decoder)
-  float *dx = nullptr, *dq = nullptr, *dlogits = nullptr, *part_o = nullptr, *part_ml = nullptr;
-  bf16_t *dattn = nullptr, *dffn = nullptr;
+  float *dx = nullptr, *dx2 = nullptr, *pend = nullptr, *dq = nullptr, *dlogits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  bf16_t *dattn = nullptr, *dffn = nullptr, *dxn = nullptr;
   int *cur_tok = nullptr, *pos = nullptr, *prompt = nullptr, *gen = nullptr, *n_done = nullptr;
   DecSeqState* state = nullptr;
   int max_prompt_cap = 0, sample_cap = 0;
@@ -110,13 +112,21 @@ struct ccx_whisper {
 
 namespace {
 
+// Weights and per-step decode buffers are carved from ONE large allocation (bump pointer, in
+// access order): large contiguous mappings keep the decode chain's weight stream on few, large
+// TLB entries and make consecutive kernels touch consecutive addresses.
 template <typename T>
 int dev_alloc(ccx_whisper* w, T** out, size_t count, bool zero) {
-  void* p = nullptr;
   const size_t bytes = ccx_align(count * sizeof(T), 256);
-  CCX_HIP(w->ctx, hipMalloc(&p, bytes));
+  void* p = nullptr;
+  if (w->arena && w->arena_off + bytes <= w->arena_cap) {
+    p = w->arena + w->arena_off;
+    w->arena_off += bytes;
+  } else {
+    CCX_HIP(w->ctx, hipMalloc(&p, bytes));
+    w->allocs.push_back(p);
+  }
   if (zero) CCX_HIP(w->ctx, hipMemset(p, 0, bytes));
-  w->allocs.push_back(p);
   *out = (T*)p;
   return CCX_OK;
 }
@@ -133,6 +143,27 @@ int up_bf16(ccx_whisper* w, bf16_t** out, const float* src, size_t n) {
   int rc = dev_alloc(w, out, n, false);
   if (rc) return rc;
   CCX_HIP(w->ctx, hipMemcpy(*out, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+
+// Decode-side weights are stored MFMA-fragment-packed for dec_linear_kernel: tile (n/16, k/32) is 64
+// consecutive 16-byte chunks, chunk l = row n0 + (l & 15), columns k0 + 8*(l >> 4) .. +8.
+// Rows are zero padded to a multiple of `row_pad`.
+int up_bf16_packed(ccx_whisper* w, bf16_t** out, const float* src, int N, int K, int row_pad) {
+  const int Np = (N + row_pad - 1) / row_pad * row_pad;
+  const int kst = K / 32;
+  std::vector<bf16_t> tmp((size_t)Np * K, 0);
+  for (int nt = 0; nt < Np / 16; nt++)
+    for (int ks = 0; ks < kst; ks++)
+      for (int l = 0; l < 64; l++) {
+        const int n = nt * 16 + (l & 15), k0 = ks * 32 + 8 * (l >> 4);
+        bf16_t* dst = &tmp[(((size_t)nt * kst + ks) * 64 + l) * 8];
+        if (n < N)
+          for (int j = 0; j < 8; j++) dst[j] = host_f32_to_bf16(src[(size_t)n * K + k0 + j]);
+      }
+  int rc = dev_alloc(w, out, tmp.size(), false);
+  if (rc) return rc;
+  CCX_HIP(w->ctx, hipMemcpy(*out, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
   return CCX_OK;
 }
 
@@ -232,6 +263,7 @@ int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch
   CCX_REQUIRE(ctx, d.n_audio_state <= 1024, "whisper: n_state > 1024 not supported yet");
   CCX_REQUIRE(ctx, d.n_audio_ctx == 1500 && d.n_mels == 80, "whisper: n_audio_ctx must be 1500 and n_mels 80");
   CCX_REQUIRE(ctx, d.n_audio_ctx % 4 == 0, "whisper: n_audio_ctx must be a multiple of 4");
+  CCX_REQUIRE(ctx, d.n_vocab % 4 == 0 && d.n_vocab <= 13 * 4096, "whisper: n_vocab must be a multiple of 4 and <= 53248");
   ccx_whisper* w = new ccx_whisper();
   w->ctx = ctx;
   w->d = d;
@@ -284,14 +316,14 @@ int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* r) {
   const int V = w->d.n_vocab;
   CCX_REQUIRE(w->ctx, r->eot >= 0 && r->eot < V && r->sot < V && r->no_speech < V && r->timestamp_begin <= V && r->blank < V &&
                           r->no_timestamps < V, "whisper: rule token id out of range");
-  std::vector<unsigned char> mask(V, 0);
+  std::vector<unsigned char> mask((size_t)V + 4, 0);
   for (int i = 0; i < r->n_suppress; i++) {
     CCX_REQUIRE(w->ctx, r->suppress[i] >= 0 && r->suppress[i] < V, "whisper: suppress id %d out of range", r->suppress[i]);
     mask[r->suppress[i]] = 1;
   }
   if (r->no_timestamps >= 0) mask[r->no_timestamps] = 1;  // ApplyTimestampRules bans <|notimestamps|>
-  if (!w->suppress_mask) TRY(dev_alloc(w, &w->suppress_mask, (size_t)V, false));
-  CCX_HIP(w->ctx, hipMemcpy(w->suppress_mask, mask.data(), V, hipMemcpyHostToDevice));
+  if (!w->suppress_mask) TRY(dev_alloc(w, &w->suppress_mask, (size_t)V + 4, false));
+  CCX_HIP(w->ctx, hipMemcpy(w->suppress_mask, mask.data(), (size_t)V + 4, hipMemcpyHostToDevice));
   w->rules = *r;
   w->rules.suppress = nullptr;
   w->rules_set = true;
@@ -304,6 +336,17 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   CCX_HIP(w->ctx, hipSetDevice(w->ctx->device));
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_audio_state, F = 4 * D, B = w->max_batch, S = d.n_audio_ctx, H = d.n_audio_head;
+  {
+    // arena for all weights (bf16 copies + fp32 vectors/embedding) and the small decode buffers
+    size_t staged = 0;
+    for (auto& kv : w->staged) staged += kv.second.data.size() * 4;
+    w->arena_cap = ccx_align(staged + ((size_t)64 << 20), (size_t)2 << 20);
+    void* base = nullptr;
+    CCX_HIP(w->ctx, hipMalloc(&base, w->arena_cap));
+    w->allocs.push_back(base);
+    w->arena = (char*)base;
+    w->arena_off = 0;
+  }
   TRY(build_logmel_tables(w));
 
   // ---------------- encoder ----------------
@@ -354,7 +397,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     NEED(lg, "decoder.ln.weight", D);
     NEED(lb, "decoder.ln.bias", D);
     TRY(up_f32(w, &w->tok_emb_f32, te->data.data(), te->data.size()));
-    TRY(up_bf16(w, &w->tok_emb_bf16, te->data.data(), te->data.size()));
+    TRY(up_bf16_packed(w, &w->tok_emb_bf16, te->data.data(), d.n_vocab, D, 64));
     TRY(up_f32(w, &w->dec_pos, pe->data.data(), pe->data.size()));
     TRY(up_f32(w, &w->lnd_g, lg->data.data(), D));
     TRY(up_f32(w, &w->lnd_b, lb->data.data(), D));
@@ -381,13 +424,13 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     std::vector<float> bqkv = cat_rows({&qbias->data, &zerosD, &vbias->data});
     std::vector<float> wckv = cat_rows({&ckw->data, &cvw->data});
     std::vector<float> bckv = cat_rows({&zerosD, &cvb->data});
-    TRY(up_bf16(w, &L.Wqkv, wqkv.data(), wqkv.size())); TRY(up_f32(w, &L.bqkv, bqkv.data(), bqkv.size()));
-    TRY(up_bf16(w, &L.Wo, ow->data.data(), ow->data.size())); TRY(up_f32(w, &L.bo, obias->data.data(), D));
-    TRY(up_bf16(w, &L.Wcq, cqw->data.data(), cqw->data.size())); TRY(up_f32(w, &L.bcq, cqb->data.data(), D));
+    TRY(up_bf16_packed(w, &L.Wqkv, wqkv.data(), 3 * D, D, 16)); TRY(up_f32(w, &L.bqkv, bqkv.data(), bqkv.size()));
+    TRY(up_bf16_packed(w, &L.Wo, ow->data.data(), D, D, 16)); TRY(up_f32(w, &L.bo, obias->data.data(), D));
+    TRY(up_bf16_packed(w, &L.Wcq, cqw->data.data(), D, D, 16)); TRY(up_f32(w, &L.bcq, cqb->data.data(), D));
     TRY(up_bf16(w, &L.Wckv, wckv.data(), wckv.size())); TRY(up_f32(w, &L.bckv, bckv.data(), bckv.size()));
-    TRY(up_bf16(w, &L.Wco, cow->data.data(), cow->data.size())); TRY(up_f32(w, &L.bco, cob->data.data(), D));
-    TRY(up_bf16(w, &L.W1, m0w->data.data(), m0w->data.size())); TRY(up_f32(w, &L.b1, m0b->data.data(), F));
-    TRY(up_bf16(w, &L.W2, m2w->data.data(), m2w->data.size())); TRY(up_f32(w, &L.b2, m2b->data.data(), D));
+    TRY(up_bf16_packed(w, &L.Wco, cow->data.data(), D, D, 16)); TRY(up_f32(w, &L.bco, cob->data.data(), D));
+    TRY(up_bf16_packed(w, &L.W1, m0w->data.data(), F, D, 16)); TRY(up_f32(w, &L.b1, m0b->data.data(), F));
+    TRY(up_bf16_packed(w, &L.W2, m2w->data.data(), D, F, 16)); TRY(up_f32(w, &L.b2, m2b->data.data(), D));
     TRY(up_f32(w, &L.ln1_g, l1g->data.data(), D)); TRY(up_f32(w, &L.ln1_b, l1b->data.data(), D));
     TRY(up_f32(w, &L.lnc_g, lcg->data.data(), D)); TRY(up_f32(w, &L.lnc_b, lcb->data.data(), D));
     TRY(up_f32(w, &L.ln2_g, l2g->data.data(), D)); TRY(up_f32(w, &L.ln2_b, l2b->data.data(), D));
@@ -415,6 +458,9 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   TRY(dev_alloc(w, &w->ffn, (size_t)B * S * F, true));
 
   TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
+  TRY(dev_alloc(w, &w->dx2, (size_t)B * D, true));
+  TRY(dev_alloc(w, &w->pend, (size_t)4 * B * D, true));
+  TRY(dev_alloc(w, &w->dxn, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dq, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dattn, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dffn, (size_t)B * F, true));
@@ -548,68 +594,83 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
 namespace {
 
 int cross_split(int B, int H) {
+  // enough blocks to fill the chip, and <= 256 keys per block (one 64-key chunk per wave)
   int ns = ccx_cdiv(512, B * H);
-  if (ns < 1) ns = 1;
+  if (ns < 6) ns = 6;
   if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
   return ns;
 }
 
 // One decoder step for B sequences on `stream`.  logits go to `logits` with row stride ld.
+// The residual stream ping-pongs between dx and dx2: out-proj / cross-out / FFN2 only write split-K
+// partial slabs (w->pend) and the next LayerNorm prologue folds them in (decoder.hip).
 int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, hipStream_t stream) {
   ccx_ctx* ctx = w->ctx;
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
   const float scale_log2e = 0.125f * 1.4426950408889634f;
   const int ns = cross_split(B, H);
-  TRY(ccx_launch_dec_embed(ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, D, stream));
+  const long pstride = (long)B * D;
+  float* cur = w->dx;     // stream (minus the pending partials); the step's embedding is in dx
+  float* other = w->dx2;
+  int pend_n = 0;
+  auto ln_linear = [&](int epi, const bf16_t* W, const float* bias, int N, const float* g, const float* bta, void* out, long ldo,
+                       DecLinearParams* extra) -> int {
+    DecLinearParams lp;
+    if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias;
+    lp.x = cur; lp.pend = w->pend; lp.pend_n = pend_n; lp.pend_stride = pstride; lp.x_out = pend_n > 0 ? other : nullptr;
+    lp.ln_g = g; lp.ln_b = bta; lp.eps = 1e-5f; lp.out = out; lp.ldo = ldo;
+    int rc = ccx_launch_dec_linear(ctx, ACT_LN, epi, lp, stream);
+    if (rc) return rc;
+    if (pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
+    return CCX_OK;
+  };
+  auto partial_linear = [&](int act, const bf16_t* W, const float* bias, int K, const bf16_t* a) -> int {
+    DecLinearParams lp;
+    memset(&lp, 0, sizeof(lp));
+    lp.M = B; lp.N = D; lp.K = K; lp.W = W; lp.ldw = K; lp.bias = bias; lp.act = a; lp.lda = K;
+    lp.part_o = w->part_o; lp.part_ml = w->part_ml; lp.nsplit = ns;
+    lp.out = w->pend; lp.ldo = D; lp.pend_stride = pstride;
+    int rc = ccx_launch_dec_linear(ctx, act, DEPI_PARTIAL, lp, stream);
+    if (rc) return rc;
+    pend_n = ccx_dec_linear_ksplit(K, DEPI_PARTIAL);
+    return CCX_OK;
+  };
   for (int l = 0; l < d.n_text_layer; l++) {
     const DecLayer& L = w->dec[l];
-    DecLinearParams lp;
     // LN + QKV, k/v appended to the self cache at pos[b]
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = 3 * D; lp.K = D; lp.W = L.Wqkv; lp.ldw = D; lp.bias = L.bqkv;
-    lp.x = w->dx; lp.ln_g = L.ln1_g; lp.ln_b = L.ln1_b; lp.eps = 1e-5f;
-    lp.out = w->dq; lp.ldo = D; lp.cache_k = L.selfK; lp.cache_v = L.selfV; lp.cache_T = Tc; lp.pos = w->pos;
-    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_SELF_QKV, lp, stream));
+    {
+      DecLinearParams ex;
+      memset(&ex, 0, sizeof(ex));
+      ex.cache_k = L.selfK; ex.cache_v = L.selfV; ex.cache_T = Tc; ex.pos = w->pos;
+      TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, w->dq, D, &ex));
+    }
     DecAttnParams ap;
     memset(&ap, 0, sizeof(ap));
     ap.q = w->dq; ap.k = L.selfK; ap.v = L.selfV; ap.H = H; ap.kv_T = Tc; ap.pos = w->pos; ap.scale_log2e = scale_log2e;
     ap.out_bf16 = w->dattn;
     TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wo; lp.ldw = D; lp.bias = L.bo; lp.act = w->dattn; lp.lda = D;
-    lp.out = w->dx; lp.ldo = D;
-    TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32_ACCUM, lp, stream));
+    TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, w->dattn));
     // cross attention
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wcq; lp.ldw = D; lp.bias = L.bcq;
-    lp.x = w->dx; lp.ln_g = L.lnc_g; lp.ln_b = L.lnc_b; lp.eps = 1e-5f; lp.out = w->dq; lp.ldo = D;
-    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_F32, lp, stream));
+    TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, w->dq, D, nullptr));
     memset(&ap, 0, sizeof(ap));
     ap.q = w->dq; ap.k = L.crossK; ap.v = L.crossV; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
     ap.scale_log2e = scale_log2e; ap.part_o = w->part_o; ap.part_ml = w->part_ml;
     TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wco; lp.ldw = D; lp.bias = L.bco;
-    lp.part_o = w->part_o; lp.part_ml = w->part_ml; lp.nsplit = ns; lp.out = w->dx; lp.ldo = D;
-    TRY(ccx_launch_dec_linear(ctx, ACT_COMBINE, DEPI_F32_ACCUM, lp, stream));
+    TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     // MLP
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = F; lp.K = D; lp.W = L.W1; lp.ldw = D; lp.bias = L.b1;
-    lp.x = w->dx; lp.ln_g = L.ln2_g; lp.ln_b = L.ln2_b; lp.eps = 1e-5f; lp.out = w->dffn; lp.ldo = F;
-    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_BF16_GELU, lp, stream));
-    memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = D; lp.K = F; lp.W = L.W2; lp.ldw = F; lp.bias = L.b2; lp.act = w->dffn; lp.lda = F;
-    lp.out = w->dx; lp.ldo = D;
-    TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32_ACCUM, lp, stream));
+    TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, w->dffn, F, nullptr));
+    TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, w->dffn));
   }
-  // final LN + logits against the tied embedding
+  // resolve the last partials + final LN, then logits against the tied embedding
+  TRY(ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, w->lnd_g, w->lnd_b, w->dxn, B, D, 1e-5f, stream));
   {
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = d.n_vocab; lp.K = D; lp.W = w->tok_emb_bf16; lp.ldw = D; lp.bias = nullptr;
-    lp.x = w->dx; lp.ln_g = w->lnd_g; lp.ln_b = w->lnd_b; lp.eps = 1e-5f; lp.out = logits; lp.ldo = ld;
-    TRY(ccx_launch_dec_linear(ctx, ACT_LN, DEPI_F32, lp, stream));
+    lp.act = w->dxn; lp.lda = D; lp.out = logits; lp.ldo = ld;
+    TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32, lp, stream));
   }
   if (select) {
     DecSelectParams sp;
@@ -619,6 +680,7 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     sp.n_done = w->n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
     sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
     sp.max_initial_ts = w->rules.max_initial_timestamp_index;
+    sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx; sp.D = D;
     TRY(ccx_launch_dec_select(ctx, sp, B, stream));
   }
   return CCX_OK;
@@ -639,6 +701,8 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
   CCX_HIP(w->ctx, hipMemcpyAsync(w->pos, ps.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->prompt, prompt_ids, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, 16, stream));
+  // embedding of the first token; later steps get theirs from the select kernel
+  TRY(ccx_launch_dec_embed(w->ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, w->d.n_text_state, stream));
   CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host vectors go out of scope
   return CCX_OK;
 }

@@ -33,6 +33,13 @@ void ccx_ctx_destroy(ccx_ctx* ctx);
  * ccx_ctx_create on this thread. */
 const char* ccx_last_error(const ccx_ctx* ctx);
 
+/* ---- per-launch timing (HIP events on the launch stream) used by bench.py's roofline ----------
+ * While enabled, every eagerly launched kernel of the library records a start/stop event pair and
+ * its algorithmic flops/bytes.  Launches inside a stream capture (graph replay) are not recorded. */
+int ccx_prof_enable(ccx_ctx* ctx, int on);  /* also clears previous records */
+int ccx_prof_count(ccx_ctx* ctx);
+int ccx_prof_get(ccx_ctx* ctx, int i, char* name_out, int name_cap, double* flops, double* bytes, float* ms);
+
 /* ---- primitive operators (exposed so tests/ can check each kernel against oracle/) ------------ */
 
 /* C[M,N] = A[M,K] * W[N,K]^T (+bias) with a fused epilogue; bf16 inputs, fp32 accumulate (MFMA).

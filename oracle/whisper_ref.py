@@ -289,3 +289,80 @@ def greedy_decode(model: WhisperRef, xa: torch.Tensor, prompts: List[List[int]],
         text = sampled[: sampled.index(rules.eot)] if rules.eot in sampled else sampled
         out.append(DecodeResult(text, sum_lp, sum_lp / (len(text) + 1), no_speech, margins))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# KV-cached incremental decoding (what openai-whisper's PyTorchInference does with its hooks):
+# same arithmetic as decoder_logits, one token per call.  Used for the timed CPU baseline and for
+# long greedy runs in tests.
+# ----------------------------------------------------------------------------------------------
+class CachedDecoder:
+    def __init__(self, model: WhisperRef, xa: torch.Tensor):
+        self.m = model
+        d = model.dims
+        self.cross = []
+        for l in range(d.n_text_layer):
+            p = f"decoder.blocks.{l}.cross_attn"
+            self.cross.append((model._lin(xa, p + ".key", bias=False), model._lin(xa, p + ".value")))
+        self.self_k = [None] * d.n_text_layer
+        self.self_v = [None] * d.n_text_layer
+        self.offset = 0
+
+    def step(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens [B, t_new] -> logits [B, t_new, V]; appends to the self-attention cache."""
+        m, d = self.m, self.m.dims
+        t_new = tokens.shape[-1]
+        x = m.sd["decoder.token_embedding.weight"][tokens] + m.sd["decoder.positional_embedding"][self.offset:self.offset + t_new]
+        T = self.offset + t_new
+        mask = torch.full((t_new, T), float("-inf")).triu_(self.offset + 1)
+        for l in range(d.n_text_layer):
+            p = f"decoder.blocks.{l}"
+            h = m._ln(x, p + ".attn_ln")
+            q = m._lin(h, p + ".attn.query")
+            k = m._lin(h, p + ".attn.key", bias=False)
+            v = m._lin(h, p + ".attn.value")
+            self.self_k[l] = k if self.self_k[l] is None else torch.cat([self.self_k[l], k], dim=1)
+            self.self_v[l] = v if self.self_v[l] is None else torch.cat([self.self_v[l], v], dim=1)
+            B, _, D = q.shape
+            nh = d.n_text_head
+            sc = (D // nh) ** -0.25
+            qh = q.view(B, t_new, nh, -1).permute(0, 2, 1, 3) * sc
+            kh = self.self_k[l].view(B, T, nh, -1).permute(0, 2, 3, 1) * sc
+            vh = self.self_v[l].view(B, T, nh, -1).permute(0, 2, 1, 3)
+            w = F.softmax((qh @ kh + mask).float(), dim=-1)
+            x = x + m._lin((w @ vh).permute(0, 2, 1, 3).flatten(start_dim=2), p + ".attn.out")
+            h = m._ln(x, p + ".cross_attn_ln")
+            q = m._lin(h, p + ".cross_attn.query")
+            ck, cv = self.cross[l]
+            x = x + m._lin(m._qkv_attention(q, ck, cv, nh), p + ".cross_attn.out")
+            x = x + m._mlp(m._ln(x, p + ".mlp_ln"), p)
+        self.offset = T
+        x = m._ln(x, "decoder.ln")
+        return (x @ m.sd["decoder.token_embedding.weight"].T).float()
+
+
+def greedy_decode_cached(model: WhisperRef, xa: torch.Tensor, prompt: List[int], rules: Rules,
+                         sample_len: int = 224) -> DecodeResult:
+    """Greedy decode of ONE sequence with the KV cache (identical filters / bookkeeping to greedy_decode)."""
+    dec = CachedDecoder(model, xa)
+    logits = dec.step(torch.tensor([prompt], dtype=torch.long))[0]
+    no_speech = F.softmax(logits[len(prompt) - 1].float(), dim=-1)[rules.no_speech].item()
+    sampled: List[int] = []
+    sum_lp = 0.0
+    margins = []
+    last = logits[-1]
+    n_tok = len(prompt)
+    for i in range(sample_len):
+        lg = apply_filters(last, sampled, rules)
+        lp = F.log_softmax(lg.float(), dim=-1)
+        top2 = torch.topk(lg, 2).values
+        margins.append(float(top2[0] - top2[1]))
+        nxt = int(lg.argmax())
+        sum_lp += float(lp[nxt])
+        sampled.append(nxt)
+        n_tok += 1
+        if nxt == rules.eot or n_tok > model.dims.n_text_ctx or i + 1 == sample_len:
+            break
+        last = dec.step(torch.tensor([[nxt]], dtype=torch.long))[0, -1]
+    text = sampled[: sampled.index(rules.eot)] if rules.eot in sampled else sampled
+    return DecodeResult(text, sum_lp, sum_lp / (len(text) + 1), no_speech, margins)
