@@ -68,6 +68,36 @@ def write_wav(path: str, audio: np.ndarray, sr: int = SAMPLE_RATE) -> None:
         w.writeframes(pcm.tobytes())
 
 
+def resample_poly_sinc(x: np.ndarray, orig_sr: int, new_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """Band-limited sinc (Hann-windowed) resampling of [channels, n] -- the algorithm of
+    torchaudio.transforms.Resample with its default arguments [UPSTREAM-RECALL], which the reference
+    applies when a file is not 16 kHz (back/api.py:824-830).  Host-side numpy: K1 is outside the
+    timed hot path for the 16 kHz benchmark clips."""
+    import math
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x[None]
+    g = math.gcd(int(orig_sr), int(new_sr))
+    o, n = int(orig_sr) // g, int(new_sr) // g
+    if o == n:
+        return x.astype(np.float32)
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = np.arange(-width, width + o, dtype=np.float64)[None, :] / o
+    t = (np.arange(0, -n, -1, dtype=np.float64)[:, None] / n + idx) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    tp = t * math.pi
+    kern = np.where(tp == 0, 1.0, np.sin(tp) / np.where(tp == 0, 1.0, tp)) * window * (base / o)   # [n, 2*width + o]
+    length = x.shape[-1]
+    xp = np.pad(x, ((0, 0), (width, width + o)))
+    n_frames = (xp.shape[-1] - kern.shape[1]) // o + 1
+    sl = np.lib.stride_tricks.sliding_window_view(xp, kern.shape[1], axis=-1)[:, ::o][:, :n_frames]   # [c, frames, taps]
+    y = np.einsum("cft,nt->cfn", sl, kern).reshape(x.shape[0], -1)
+    target = int(math.ceil(n * length / o))
+    return y[:, :target].astype(np.float32)
+
+
 # 30 s activity schedule of the synthetic benchmark clips (SURVEY.md section 8d)
 SCHEDULE_30S = [("A", 0.0, 9.0), ("B", 7.0, 16.0), ("A", 18.0, 24.0), ("B", 26.0, 30.0)]
 SCHEDULE_10S = [("A", 0.0, 6.0), ("B", 4.0, 10.0)]

@@ -1,0 +1,523 @@
+"""Host-side mirror of the reference's pipeline orchestrator.
+
+`EnhancedAudioProcessor` here is a work-alike (not a copy) of the class the reference defines at
+/root/reference/back/api.py:584-1549: same constructor, `run`, `process_file`, `models_are_loaded`,
+`load_models_with_progress`, the same `Config` / `AudioSegment` fields and the same decisions for
+every input, checked against fixtures produced by executing the reference's own code
+(oracle/gen_glue_golden.py -> tests/golden/glue_*.json).
+
+The five model objects it drives are duck-typed exactly as in the reference:
+    whisper_model.transcribe(np1d, initial_prompt=, word_timestamps=, condition_on_previous_text=, temperature=)['text']
+    separator.separate_batch(Tensor[1,T]) -> Tensor[1,T,2]
+    embedding_model({"waveform": Tensor[1,T], "sample_rate": int}) -> ndarray/Tensor [D]
+    vad_pipeline(path) / diarization(path, min_speakers=, max_speakers=) -> object with itertracks(yield_label=True)
+    denoiser(np1d, sr, prop_decrease) -> np1d            (noisereduce.reduce_noise in the reference)
+In the product they are the libccx-backed objects built by `clearconverse_amd.models.load_models`;
+tests inject scripted stubs through the same attributes.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import tempfile
+import traceback
+from collections import Counter
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import intervals as iv
+from .audio import read_wav, resample_poly_sinc, write_wav
+
+log = logging.getLogger("clearconverse_amd")
+
+PROMPT_TWO_PEOPLE = "This is a conversation between two people."
+PROMPT_COMPLETE = "This is a clear conversation with complete sentences."
+PROMPT_FAST = "This is a fast-paced conversation with quick speaker changes. "
+PROMPT_SINGLE = "This is a single speaker talking."
+
+
+@dataclass
+class AudioSegment:  # reference back/api.py:101-110
+    start: float
+    end: float
+    speaker_id: str
+    audio_tensor: torch.Tensor
+    is_overlap: bool = False
+    transcription: Optional[str] = None
+    confidence: float = 1.0
+    metadata: Dict[str, Any] = field(default_factory=dict)
+
+
+@dataclass
+class Config:  # reference back/api.py:112-135 -- same names, same defaults (dead knobs kept for drop-in)
+    auth_token: str = ""
+    target_sample_rate: int = 16000
+    min_segment_duration: float = 0.45
+    overlap_threshold: float = 0.50
+    condition_on_previous_text: bool = True
+    merge_gap_threshold: float = 0.50
+    min_overlap_duration_for_separation: float = 0.50
+    max_embedding_segments: int = 100
+    enhance_separated_audio: bool = True
+    use_vad_refinement: bool = True
+    speaker_embedding_threshold: float = 0.40
+    noise_reduction_amount: float = 0.50
+    transcription_batch_size: int = 8
+    use_speaker_embeddings: bool = True
+    temperature: float = 0.1
+    max_speakers: int = 2
+    min_speakers: int = 1
+    whisper_model_size: str = "small.en"
+    transcribe_overlaps_individually: bool = True
+    sliding_window_size: float = 0.80
+    sliding_window_step: float = 0.40
+    secondary_diarization_threshold: float = 0.30
+
+
+def _tracks(annotation) -> List[Tuple[float, float, str]]:
+    return [(seg.start, seg.end, label) for seg, _, label in annotation.itertracks(yield_label=True)]
+
+
+class EnhancedAudioProcessor:
+    def __init__(self, config: Config, load_models_immediately: bool = False, model_loader: Optional[Callable] = None):
+        self.config = config
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.resampler = None
+        self.models_loaded = {"whisper": False, "resepformer": False, "pyannote": False}
+        self._model_loader = model_loader
+        self.denoiser: Optional[Callable] = None
+        if load_models_immediately:
+            self._initialize_models()
+
+    # ------------------------------------------------------------------ model lifecycle
+    def _loader(self):
+        if self._model_loader is not None:
+            return self._model_loader
+        from .models import load_models  # libccx-backed objects; raises loudly without the HIP library / GPU
+        return load_models
+
+    def _initialize_models(self):
+        objs = self._loader()(self.config, self.device)
+        for name in ("whisper_model", "separator", "embedding_model", "vad_pipeline", "diarization", "denoiser"):
+            setattr(self, name, objs[name])
+        self.models_loaded = {k: True for k in self.models_loaded}
+
+    def load_models_with_progress(self, progress_callback=None) -> bool:
+        """Same progress protocol as reference back/api.py:617-652 (5/10/35/60/90, or 100 + error text)."""
+        def tell(pct, msg):
+            if progress_callback:
+                progress_callback(pct, msg)
+        try:
+            tell(5, "Initializing model environment...")
+            objs = None
+            stages = (("resepformer", 10, "Loading RESepFormer...", ("separator",)),
+                      ("whisper", 35, "Loading Whisper...", ("whisper_model",)),
+                      ("pyannote", 60, "Loading speaker diarization tool...", ("embedding_model", "vad_pipeline", "diarization", "denoiser")))
+            for key, pct, msg, attrs in stages:
+                if self.models_loaded[key]:
+                    continue
+                tell(pct, msg)
+                if objs is None:
+                    objs = self._loader()(self.config, self.device)
+                for a in attrs:
+                    setattr(self, a, objs[a])
+                self.models_loaded[key] = True
+            tell(90, "Models loaded, preparing for processing...")
+            return True
+        except Exception as e:  # noqa: BLE001 -- the reference reports and returns False
+            log.error("Error loading models: %s", e)
+            tell(100, f"Error loading models: {e}")
+            return False
+
+    def models_are_loaded(self) -> bool:
+        return all(self.models_loaded.values())
+
+    # ------------------------------------------------------------------ audio front end (A3-A5)
+    def _denoise(self, x: np.ndarray, prop_decrease: float) -> np.ndarray:
+        if self.denoiser is None:
+            raise RuntimeError("no denoiser loaded (the spectral gate is part of the model set)")
+        return np.asarray(self.denoiser(x, self.config.target_sample_rate, prop_decrease))
+
+    def load_audio(self, file_path: str) -> Tuple[torch.Tensor, int]:
+        """reference back/api.py:799-838: load -> mono -> 16 kHz -> stationary spectral gate -> peak 1."""
+        sr_t = self.config.target_sample_rate
+        path = file_path
+        if path.lower().endswith(".mp3"):
+            wav = path[:-4] + ".wav"
+            if os.path.exists(wav):
+                path = wav
+            else:
+                raise RuntimeError("MP3 input needs an ffmpeg-converted WAV next to it (codec is out of scope)")
+        sig, sr = read_wav(path)
+        if sig.shape[0] > 1:
+            sig = sig.mean(axis=0, keepdims=True)
+        if sr != sr_t:
+            sig = resample_poly_sinc(sig, sr, sr_t)
+        x = sig.reshape(-1).astype(np.float32)
+        x = self._denoise(x, self.config.noise_reduction_amount)
+        x = x / (np.max(np.abs(x)) + 1e-8)
+        return torch.tensor(x, dtype=torch.float32, device=self.device).unsqueeze(0), sr_t
+
+    def _extract_segment(self, audio: torch.Tensor, start: float, end: float, sample_rate: Optional[int] = None) -> torch.Tensor:
+        sr = sample_rate or self.config.target_sample_rate
+        total = audio.shape[-1] / sr
+        start = 0.0 if start < 0 else start
+        end = total if end > total else end
+        i0, i1 = int(start * sr), int(end * sr)
+        if i0 >= i1:
+            return torch.zeros((1, 100), device=self.device)
+        return audio[:, i0:i1]
+
+    def _enhance(self, crop: torch.Tensor, prop_decrease: float) -> torch.Tensor:
+        """module-level enhance_audio of the reference (back/api.py:345-352): gate, then peak-normalise."""
+        x = crop.detach().cpu().numpy()
+        if x.ndim > 1:
+            x = x.squeeze()
+        y = self._denoise(x, prop_decrease)
+        peak = np.max(np.abs(y))
+        if peak > 0:
+            y = y / peak
+        return torch.tensor(y, dtype=torch.float32)
+
+    # ------------------------------------------------------------------ speaker embeddings (A6-A8)
+    def _extract_embedding(self, crop: torch.Tensor) -> Optional[torch.Tensor]:
+        try:
+            if crop.shape[-1] < self.config.target_sample_rate / 2:
+                return None
+            wave = crop.detach().cpu()
+            if wave.dim() == 1:
+                wave = wave.unsqueeze(0)
+            emb = self.embedding_model({"waveform": torch.from_numpy(wave.numpy()), "sample_rate": self.config.target_sample_rate})
+            if isinstance(emb, torch.Tensor):
+                return emb.to(self.device)
+            return torch.tensor(emb, device=self.device)
+        except Exception as e:  # noqa: BLE001
+            log.error("Error in embedding extraction: %s", e)
+            return None
+
+    @staticmethod
+    def _calculate_embedding_similarity(a: torch.Tensor, b: torch.Tensor) -> float:
+        return torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+
+    def _build_speaker_profiles(self, audio: torch.Tensor, diarization_result) -> Dict[str, torch.Tensor]:
+        cfg = self.config
+        if not cfg.use_speaker_embeddings:
+            return {}
+        by_speaker: Dict[str, List[Tuple[float, float, float]]] = {}
+        for s, e, lab in _tracks(diarization_result):
+            if (e - s) >= 0.75:
+                by_speaker.setdefault(lab, []).append((s, e, e - s))
+        half = cfg.max_embedding_segments // 2
+        profiles: Dict[str, torch.Tensor] = {}
+        for lab, segs in by_speaker.items():
+            longest = sorted(segs, key=lambda t: t[2], reverse=True)[:half]
+            rest = sorted([t for t in segs if t not in longest], key=lambda t: t[0])
+            stride = max(1, len(rest) // half)
+            chosen = longest + rest[::stride][:half]
+            embs: List[torch.Tensor] = []
+            quality: List[float] = []
+            for s, e, _ in chosen:
+                crop = self._extract_segment(audio, s, e)
+                if crop.shape[-1] > cfg.target_sample_rate * 0.5:
+                    emb = self._extract_embedding(self._enhance(crop, cfg.noise_reduction_amount))
+                    if emb is not None:
+                        embs.append(emb)
+                        quality.append(torch.var(crop).item())
+            if not embs:
+                continue
+            total = sum(quality)
+            if total > 0:
+                profiles[lab] = sum(e * (q / total) for e, q in zip(embs, quality))
+            else:
+                profiles[lab] = torch.stack(embs).mean(dim=0)
+        return profiles
+
+    # ------------------------------------------------------------------ overlap handling (A10-A12)
+    def _detect_overlap_regions(self, diarization_result) -> List[Tuple[float, float, List[str]]]:
+        found = iv.find_segment_overlaps(_tracks(diarization_result))
+        thr = self.config.overlap_threshold
+        return [(s, e, spk) for (s, e), spk in found.items() if (e - s) >= thr and len(spk) > 1]
+
+    def _resegment_overlap(self, audio_segment: torch.Tensor, seg_start: float, seg_end: float,
+                           speaker_profiles: Dict[str, torch.Tensor]) -> List[Tuple[float, float, str]]:
+        """Sliding-window speaker attribution inside an overlap-bearing segment (reference 961-1050)."""
+        cfg = self.config
+        win, hop = cfg.sliding_window_size, cfg.sliding_window_step
+        span = seg_end - seg_start
+        if span < 2.0:
+            hop = min(hop, span / 4)
+        votes: List[Tuple[float, float, str, float]] = []
+        pos = seg_start
+        prev: Optional[str] = None
+        while pos + win <= seg_end:
+            emb = self._extract_embedding(self._extract_segment(audio_segment, pos - seg_start, pos - seg_start + win))
+            if emb is None:
+                who, conf = (prev if prev else "UNKNOWN"), 0.0
+            else:
+                ranked = sorted(((lab, self._calculate_embedding_similarity(emb, prof)) for lab, prof in speaker_profiles.items()),
+                                key=lambda t: t[1], reverse=True)
+                who, conf = ranked[0]          # IndexError with no profiles, exactly as the reference (api.py:984)
+                if len(ranked) > 1:
+                    second, second_conf = ranked[1]
+                    if (conf - second_conf) < 0.15 and prev and prev != who:
+                        if second == prev and second_conf > 0.65 * conf:
+                            who, conf = prev, second_conf
+                prev = who
+            votes.append((pos, pos + win, who, conf))
+            pos += hop
+        if not votes:
+            return [(seg_start, seg_end, "UNKNOWN")]
+        floor = min(0.3, span / 10)
+        joined: List[Tuple[float, float, str]] = []
+        a, b, who, conf = votes[0]
+        for s, e, w, c in votes[1:]:
+            if w == who and s - b <= max(hop * 1.5, 0.2):
+                b = e
+                conf = (conf + c) / 2
+            else:
+                if (b - a) >= floor:
+                    joined.append((a, b, who))
+                a, b, who, conf = s, e, w, c
+        if (b - a) >= floor:
+            joined.append((a, b, who))
+        final: List[Tuple[float, float, str]] = []
+        for i, (s, e, w) in enumerate(joined):
+            s2, e2 = max(seg_start, s), min(seg_end, e)
+            if e2 - s2 < floor and i > 0:
+                ps, pe, pw = final[-1]
+                if pe - ps > floor * 1.5:
+                    need = floor - (e2 - s2)
+                    pe -= min(need, pe - ps - floor)
+                    s2 = pe
+                    final[-1] = (ps, pe, pw)
+            if e2 - s2 >= floor:
+                final.append((s2, e2, w))
+        return [(max(seg_start, s), min(seg_end, e), w) for s, e, w in final]
+
+    def _diarize(self, file_path, min_speakers, max_speakers):
+        try:
+            return self.diarization(file_path, min_speakers=min_speakers, max_speakers=max_speakers)
+        except Exception as e:  # noqa: BLE001
+            log.error("Error in diarization: %s", e)
+            raise
+
+    def _process_overlap_segment(self, audio_segment: torch.Tensor, speaker_embeddings: Dict[str, torch.Tensor],
+                                 involved_speakers: List[str], seg_start: float, seg_end: float) -> List[Dict]:
+        out: List[Dict] = []
+        for ns, ne, who in self._resegment_overlap(audio_segment, seg_start, seg_end, speaker_embeddings):
+            piece = self._extract_segment(audio_segment, ns - seg_start, ne - seg_start)
+            try:
+                sources = self.separator.separate_batch(piece)
+                best, best_sim = None, -1.0
+                for k in range(sources.shape[-1]):
+                    src = sources[..., k]
+                    src = src / (torch.max(torch.abs(src)) + 1e-8)
+                    emb = self._extract_embedding(src)
+                    if emb is None:
+                        continue
+                    sim = self._calculate_embedding_similarity(emb, speaker_embeddings.get(who, emb))
+                    if sim > best_sim:
+                        best, best_sim = src, sim
+                chosen = best if best is not None else piece
+                text = self._transcribe(chosen.squeeze().cpu().numpy(), initial_prompt=PROMPT_SINGLE,
+                                        temperature=self.config.temperature)["text"]
+                out.append({"audio": chosen, "transcription": text, "speaker_id": who, "confidence": best_sim})
+            except Exception as e:  # noqa: BLE001 -- the reference keeps going with a marker segment
+                log.error("Error processing overlap subsegment: %s", e)
+                out.append({"audio": piece, "transcription": "[Processing error]", "speaker_id": who,
+                            "confidence": 0.0, "error": str(e)})
+        return out
+
+    def _secondary_diarization(self, audio_segment: torch.Tensor, seg_start: float, seg_end: float) -> List[Tuple[float, float, str]]:
+        """Second diarization pass over one crop (reference 1120-1137).  The reference writes
+        `temp_segment.wav` into the CWD; here it goes into a private temp dir (same basename) so
+        concurrent tasks cannot clobber each other."""
+        try:
+            with tempfile.TemporaryDirectory(prefix="ccx_seg_") as td:
+                path = os.path.join(td, "temp_segment.wav")
+                write_wav(path, audio_segment.detach().cpu().numpy(), self.config.target_sample_rate)
+                ann = self.diarization(path, min_speakers=1, max_speakers=2)
+            found = _tracks(ann)
+            if not found:
+                return [(seg_start, seg_end, "UNKNOWN")]
+            return iv.merge_diarization_segments(found, self.config.merge_gap_threshold)
+        except Exception as e:  # noqa: BLE001
+            log.error("Secondary diarization failed: %s", e)
+            return [(seg_start, seg_end, "UNKNOWN")]
+
+    # ------------------------------------------------------------------ outputs (A17)
+    def save_segments(self, segments: Sequence[AudioSegment], output_dir: str):
+        base = Path(output_dir)
+        regular, overlap = base / "regular_segments", base / "overlap_segments"
+        regular.mkdir(parents=True, exist_ok=True)
+        overlap.mkdir(parents=True, exist_ok=True)
+        for s in segments:
+            stamp = f"{s.start:.2f}-{s.end:.2f}"
+            target = (overlap / f"overlap_{stamp}_{s.speaker_id}.wav") if s.is_overlap else (regular / f"{stamp}_{s.speaker_id}.wav")
+            write_wav(str(target), s.audio_tensor.detach().cpu().numpy(), self.config.target_sample_rate)
+
+    @staticmethod
+    def format_transcript(segments: Sequence[AudioSegment]) -> str:
+        """The output contract the front end parses (reference back/api.py:1255-1257)."""
+        return "".join(f"[{s.speaker_id}] {s.start:.2f}s - {s.end:.2f}s\n{s.transcription}\n\n" for s in segments)
+
+    def run(self, input_file, output_dir: str = "processed_audio", debug_mode: bool = False, progress_callback=None):
+        def tell(pct, msg):
+            if progress_callback:
+                progress_callback(pct, msg)
+        try:
+            tell(5, "Starting processing")
+            if not self.models_are_loaded() and not self.load_models_with_progress(progress_callback):
+                return None, None, None
+            os.makedirs(output_dir, exist_ok=True)
+            tell(30, "Running file processing")
+            results = self.process_file(input_file)
+            if results is None:
+                return None, None, None
+            tell(60, "Saving processed segments")
+            segs = results.get("segments")
+            if not segs:
+                return None, None, None
+            if not any(s.transcription and s.transcription.strip() for s in segs):
+                return None, None, None
+            self.save_segments(segs, output_dir)
+            tell(80, "Saving transcript")
+            transcript = self.format_transcript(segs)
+            if not transcript.strip():
+                return None, None, None
+            path = os.path.join(output_dir, "transcript.txt")
+            with open(path, "w", encoding="utf-8") as f:
+                f.write(transcript)
+            tell(100, "Processing completed")
+            return input_file, transcript, path
+        except Exception as e:  # noqa: BLE001
+            log.error("Error during processing: %s", e)
+            traceback.print_exc()
+            raise
+
+    def _transcribe(self, audio_np, initial_prompt="", word_timestamps=False, condition_on_previous_text=True, temperature=0.0):
+        try:
+            return self.whisper_model.transcribe(audio_np, initial_prompt=initial_prompt, word_timestamps=word_timestamps,
+                                                 condition_on_previous_text=condition_on_previous_text, temperature=temperature)
+        except Exception as e:  # noqa: BLE001
+            log.error("Error in whisper transcription: %s", e)
+            raise RuntimeError(f"Transcription failed: {e}")
+
+    # ------------------------------------------------------------------ the hot path (A1)
+    def process_file(self, file_path: str) -> Optional[Dict]:
+        try:
+            return self._process_file(file_path)
+        except Exception as e:  # noqa: BLE001 -- process_file never raises (reference 1546-1549)
+            log.error("Error in process_file: %s", e)
+            if log.isEnabledFor(logging.DEBUG):
+                traceback.print_exc()
+            return None
+
+    def _process_file(self, file_path: str) -> Dict:
+        cfg = self.config
+        wav_path = file_path[:-4] + ".wav" if file_path.lower().endswith(".mp3") and os.path.exists(file_path[:-4] + ".wav") else file_path
+        audio, sr = self.load_audio(file_path)
+        duration = audio.shape[-1] / sr
+
+        vad_intervals = iv.get_vad_intervals(self.vad_pipeline(wav_path))
+        diar = self._diarize(wav_path, min_speakers=cfg.min_speakers, max_speakers=cfg.max_speakers)
+        merged = iv.merge_diarization_segments(_tracks(diar), cfg.merge_gap_threshold)
+        if cfg.use_vad_refinement:
+            segs = []
+            for s, e, lab in merged:
+                r = iv.refine_segment_with_vad((s, e), vad_intervals)
+                if r and (r[1] - r[0] >= cfg.min_segment_duration):
+                    segs.append((r[0], r[1], lab))
+        else:
+            segs = merged
+
+        profiles = self._build_speaker_profiles(audio, diar)
+
+        counts = Counter(lab for _, _, lab in segs)
+        if len(counts) < 2:
+            labels = list(counts.keys())
+            if not labels:
+                raise ValueError("No speakers detected in the audio file")
+            names = {labels[0]: "SPEAKER_A"}
+        else:
+            top = [lab for lab, _ in counts.most_common(2)]
+            names = {top[0]: "SPEAKER_A", top[1]: "SPEAKER_B"}
+
+        overlaps = self._detect_overlap_regions(diar)
+        segs.sort(key=lambda t: t[0])
+
+        out: List[AudioSegment] = []
+        tally = {"SPEAKER_A": 0, "SPEAKER_B": 0}
+        prev_end: float = 0
+        prev_spk: Optional[str] = None
+        prev_text = ""
+
+        for seg_start, seg_end, orig in segs:
+            if (seg_end - seg_start) < cfg.min_segment_duration:
+                continue
+            involved: List[str] = []
+            in_overlap = False
+            for os_, oe, who in overlaps:
+                if max(seg_start, os_) < min(seg_end, oe):
+                    in_overlap, involved = True, who
+                    break
+            crop = self._extract_segment(audio, seg_start, seg_end)
+            label = names.get(orig, "UNKNOWN")
+            rapid = prev_spk is not None and prev_spk != orig and 0 < (seg_start - prev_end) < 0.5
+
+            if in_overlap:
+                prev_spk, prev_text = None, ""
+                mapped = {names.get(k, k): v for k, v in profiles.items()}
+                for r in self._process_overlap_segment(crop, mapped, [names.get(s, s) for s in involved], seg_start, seg_end):
+                    out.append(AudioSegment(start=seg_start, end=seg_end, speaker_id=r["speaker_id"], audio_tensor=r["audio"],
+                                            is_overlap=True, transcription=r["transcription"],
+                                            confidence=r.get("confidence", 0.5), metadata={"overlap_speakers": involved}))
+                prev_end = seg_end
+                continue
+
+            emb = self._extract_embedding(crop)
+            if emb is not None:
+                prof = profiles.get(orig)
+                sim = self._calculate_embedding_similarity(emb, prof) if prof is not None else 0
+                if sim < cfg.secondary_diarization_threshold:
+                    for ns, ne, nspk in self._secondary_diarization(crop, seg_start, seg_end):
+                        sub = self._extract_segment(crop, ns - seg_start, ne - seg_start)
+                        prompt = PROMPT_COMPLETE
+                        if nspk == prev_spk and seg_start - prev_end < 1.0:
+                            prompt = f"{prev_text.strip()} "
+                        if rapid:
+                            prompt = PROMPT_FAST
+                        text = self.whisper_model.transcribe(sub.squeeze().cpu().numpy(), initial_prompt=prompt, word_timestamps=True,
+                                                             condition_on_previous_text=cfg.condition_on_previous_text,
+                                                             temperature=cfg.temperature)["text"]
+                        final = names.get(nspk, label)
+                        out.append(AudioSegment(start=seg_start + ns, end=seg_start + ne, speaker_id=final, audio_tensor=sub,
+                                                is_overlap=False, transcription=text, confidence=1.0,
+                                                metadata={"rapid_exchange": rapid}))
+                        tally[final] = tally.get(final, 0) + 1
+                        prev_end, prev_spk, prev_text = seg_start + ne, nspk, text
+                    continue
+
+            prompt = PROMPT_TWO_PEOPLE
+            if orig == prev_spk and seg_start - prev_end < 1.0:
+                prompt = f"{prev_text.strip()} "
+            if rapid:
+                prompt = PROMPT_FAST
+            text = self.whisper_model.transcribe(crop.squeeze().cpu().numpy(), initial_prompt=prompt, word_timestamps=True,
+                                                 condition_on_previous_text=cfg.condition_on_previous_text,
+                                                 temperature=cfg.temperature)["text"]
+            out.append(AudioSegment(start=seg_start, end=seg_end, speaker_id=label, audio_tensor=crop, is_overlap=False,
+                                    transcription=text, confidence=1.0, metadata={"rapid_exchange": rapid}))
+            tally[label] = tally.get(label, 0) + 1
+            prev_end, prev_spk, prev_text = seg_end, orig, text
+
+        out.sort(key=lambda s: s.start)
+        meta = {"duration": duration, "speaker_a_segments": tally.get("SPEAKER_A", 0),
+                "speaker_b_segments": tally.get("SPEAKER_B", 0), "total_segments": len(out),
+                "speakers": list(names.values()),
+                "rapid_exchanges": sum(1 for s in out if s.metadata.get("rapid_exchange", False))}
+        return {"segments": out, "metadata": meta}

@@ -1,0 +1,125 @@
+"""CPU: clearconverse_amd.processor / intervals against fixtures produced by EXECUTING the
+reference's own glue code (oracle/gen_glue_golden.py, reference back/api.py:294-343, 584-1549) with
+the scripted stub models of tests/glue_stubs.py.  Same stubs here -> results must be identical."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from clearconverse_amd import intervals as iv
+from clearconverse_amd.processor import AudioSegment, Config, EnhancedAudioProcessor
+from tests.glue_stubs import (Annotation, Scenario, StubEmbedding, StubSeparator, StubWhisper, result_to_json, scenario_audio)
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+INTERVALS = json.loads((GOLDEN / "glue_intervals.json").read_text())
+PROCESS = json.loads((GOLDEN / "glue_process_file.json").read_text())
+
+
+@pytest.mark.parametrize("idx", range(len(INTERVALS["cases"])))
+def test_interval_helpers_match_reference(idx):
+    c = INTERVALS["cases"][idx]
+    segs = [tuple(x) for x in c["input"]["segments"]]
+    vad = [tuple(v) for v in c["input"]["vad"]]
+    assert [list(m) for m in iv.merge_diarization_segments(list(segs), c["input"]["gap"])] == c["merged"]
+    ov = iv.find_segment_overlaps(list(segs))
+    assert sorted([[k[0], k[1], sorted(v)] for k, v in ov.items()]) == c["overlaps"]
+    got = [iv.refine_segment_with_vad((s, e), vad) for s, e, _ in segs]
+    assert [list(r) if r is not None else None for r in got] == c["refined"]
+
+
+def _build(sc: Scenario):
+    cfg = Config(auth_token="x", **sc.config)
+    p = EnhancedAudioProcessor(cfg, load_models_immediately=False)
+    p.device = torch.device("cpu")
+    audio = scenario_audio(sc)
+    p.load_audio = lambda path: (audio.clone(), 16000)
+    p.whisper_model = StubWhisper()
+    p.separator = StubSeparator()
+    p.embedding_model = StubEmbedding()
+    p.denoiser = lambda y, sr, prop_decrease: np.asarray(y)        # same identity stub the reference run used for nr.reduce_noise
+    p.vad_pipeline = lambda path: Annotation([(s, e, "SPEECH") for s, e in sc.vad])
+    calls = []
+
+    def diar(path, min_speakers=None, max_speakers=None):
+        calls.append(os.path.basename(str(path)))
+        return Annotation(list(sc.secondary if os.path.basename(str(path)) == "temp_segment.wav" else sc.diarization))
+    p.diarization = diar
+    p.models_loaded = {k: True for k in p.models_loaded}
+    return p, calls
+
+
+def _close(a, b, path=""):
+    if isinstance(a, float) or isinstance(b, float):
+        assert a == pytest.approx(b, rel=1e-6, abs=1e-7), path
+    elif isinstance(a, dict):
+        assert set(a) == set(b), (path, set(a) ^ set(b))
+        for k in a:
+            _close(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, list):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _close(x, y, f"{path}[{i}]")
+    else:
+        assert a == b, path
+
+
+@pytest.mark.parametrize("name", sorted(PROCESS["scenarios"]))
+def test_process_file_matches_reference(name):
+    entry = PROCESS["scenarios"][name]
+    sc = Scenario.from_json(entry["scenario"])
+    p, diar_calls = _build(sc)
+    res = p.process_file("clip.wav")
+    got = result_to_json(res, p.whisper_model.calls, p.separator.calls, diar_calls)
+    exp = dict(entry["expected"])
+    transcript = exp.pop("transcript", None)
+    _close(json.loads(json.dumps(got)), exp, name)
+    if res is not None:
+        assert EnhancedAudioProcessor.format_transcript(res["segments"]) == transcript
+
+
+def test_config_mirrors_reference_defaults():
+    c = Config(auth_token="t")
+    assert (c.target_sample_rate, c.min_segment_duration, c.overlap_threshold, c.merge_gap_threshold) == (16000, 0.45, 0.5, 0.5)
+    assert (c.max_embedding_segments, c.noise_reduction_amount, c.temperature, c.max_speakers, c.min_speakers) == (100, 0.5, 0.1, 2, 1)
+    assert (c.sliding_window_size, c.sliding_window_step, c.secondary_diarization_threshold, c.whisper_model_size) == (0.8, 0.4, 0.3, "small.en")
+
+
+def test_run_writes_transcript_and_segments(tmp_path):
+    sc = Scenario.from_json(PROCESS["scenarios"]["two_speakers_overlap_10s"]["scenario"])
+    p, _ = _build(sc)
+    seen = []
+    src, transcript, path = p.run("clip.wav", output_dir=str(tmp_path / "out"), progress_callback=lambda pct, msg: seen.append(pct))
+    assert src == "clip.wav" and os.path.exists(path)
+    assert open(path, encoding="utf-8").read() == transcript == PROCESS["scenarios"]["two_speakers_overlap_10s"]["expected"]["transcript"]
+    assert seen[0] == 5 and seen[-1] == 100 and 30 in seen and 60 in seen and 80 in seen
+    assert len(list((tmp_path / "out" / "overlap_segments").glob("overlap_*.wav"))) == 3
+
+
+def test_run_returns_none_tuple_when_nothing_detected(tmp_path):
+    sc = Scenario.from_json(PROCESS["scenarios"]["no_speakers"]["scenario"])
+    p, _ = _build(sc)
+    assert p.run("clip.wav", output_dir=str(tmp_path / "o")) == (None, None, None)
+
+
+def test_extract_segment_edge_cases():
+    p = EnhancedAudioProcessor(Config(), load_models_immediately=False)
+    p.device = torch.device("cpu")
+    a = torch.arange(32000, dtype=torch.float32)[None]
+    assert p._extract_segment(a, -1.0, 0.5).shape == (1, 8000)
+    assert p._extract_segment(a, 1.5, 9.0).shape == (1, 8000)          # clipped to the 2.0 s clip
+    assert p._extract_segment(a, 1.0, 1.0).shape == (1, 100)           # invalid -> zeros(1,100), reference 855-858
+    assert p._extract_embedding(torch.zeros(1, 7999)) is None          # < 0.5 s -> no embedding, reference 864-866
+
+
+def test_resampler_matches_known_properties():
+    from clearconverse_amd.audio import resample_poly_sinc
+    t = np.arange(8000) / 8000.0
+    x = np.sin(2 * np.pi * 440 * t).astype(np.float32)[None]
+    y = resample_poly_sinc(x, 8000, 16000)
+    assert y.shape == (1, 16000)
+    ref = np.sin(2 * np.pi * 440 * np.arange(16000) / 16000.0)
+    assert np.abs(y[0, 200:-200] - ref[200:-200]).max() < 2e-3
+    assert np.array_equal(resample_poly_sinc(x, 16000, 16000), x)
