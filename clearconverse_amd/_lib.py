@@ -25,6 +25,11 @@ class WhisperDims(C.Structure):
         "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
 
 
+class SepformerDims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "n_filters", "kernel", "stride", "d_model", "n_head", "d_ffn", "n_layers", "n_blocks", "segment", "n_spk")]
+
+
 class DecodeRules(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "eot", "sot", "sot_prev", "no_speech", "no_timestamps", "timestamp_begin", "blank",
@@ -59,6 +64,11 @@ PROTOTYPES = {
     "ccx_whisper_encode": (_i, [_vp, _i, _vp, _vp]),
     "ccx_whisper_decoder_logits": (_i, [_vp, _i32p, _i, _i, _vp, _vp]),
     "ccx_whisper_decode_greedy": (_i, [_vp, _i32p, _i32p, _i, _i, _i, _i32p, _i32p, _fp, _fp, _vp]),
+    "ccx_sepformer_create": (_i, [_vp, C.POINTER(SepformerDims), _i, _i, C.POINTER(_vp)]),
+    "ccx_sepformer_destroy": (None, [_vp]),
+    "ccx_sepformer_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i64]),
+    "ccx_sepformer_finalize": (_i, [_vp]),
+    "ccx_sepformer_separate": (_i, [_vp, _vp, _i64, _ip, _i, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

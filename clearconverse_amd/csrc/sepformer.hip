@@ -1,0 +1,590 @@
+// sepformer.hip -- RE-SepFormer separator of libccx (K12-K17 in SURVEY.md section 2a).
+//
+// Replaces `self.separator.separate_batch(mix[1,T]) -> [1,T,2]` (reference back/api.py:1077; model
+// speechbrain/resepformer-wsj02mix loaded at back/api.py:713).  Semantics follow SpeechBrain
+// [UPSTREAM-RECALL]; the CPU restatement is oracle/sepformer_ref.py.
+//
+// Data layout: all utterances of a call are concatenated into ONE token buffer [n_tok, 128] (every
+// utterance padded to whole 150-token chunks, as the reference's _padfeature does), so the segment
+// transformer's GEMMs / LayerNorms run flat over all chunks of all utterances (ragged batches cost
+// nothing) on the shared bf16 MFMA GEMM (gemm_bf16.hip).  Sequences (chunks for the segment model,
+// one chunk-mean sequence per utterance for the memory model) are described by a (start, len)
+// table consumed by the attention / global-norm kernels.
+#include <map>
+#include <math.h>
+#include "../../include/ccx.h"
+#include "ccx_common.h"
+#include "elementwise.h"
+#include "gemm_bf16.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short bf16x4v;
+
+// ---------------------------------------------------------------------------------------------
+// Encoder: Conv1d(1 -> N=128, k=16, stride 8, no bias) + ReLU, written token-major [tok, 128] f32.
+// Rows that are chunk padding are zero-filled.  One wave per token (2 filters per lane).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sep_encoder_kernel(const float* __restrict__ mix, long mix_stride,
+                                                          const int* __restrict__ tok_utt, const int* __restrict__ tok_pos,
+                                                          const int* __restrict__ utt_L, const float* __restrict__ w,  // [128][16]
+                                                          float* __restrict__ feats, int n_tok) {
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (tok >= n_tok) return;
+  const int u = tok_utt[tok], l = tok_pos[tok];
+  float2 o = make_float2(0.f, 0.f);
+  if (l < utt_L[u]) {
+    const float* x = mix + (long)u * mix_stride + 8 * l;
+    float xs[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) xs[k] = x[k];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      a = fmaf(w[(2 * lane) * 16 + k], xs[k], a);
+      b = fmaf(w[(2 * lane + 1) * 16 + k], xs[k], b);
+    }
+    o = make_float2(fmaxf(a, 0.f), fmaxf(b, 0.f));
+  }
+  ((float2*)(feats + (long)tok * 128))[lane] = o;
+}
+
+// x' = x (+ hc[seq]) ; h = x' + pe[pos]   (block input and its positionally encoded stream)
+__global__ void sep_block_input_kernel(const float* __restrict__ x, const float* __restrict__ hc, const int* __restrict__ tok_seq,
+                                       const int* __restrict__ tok_pos, const float* __restrict__ pe, float* __restrict__ xin,
+                                       float* __restrict__ h, int n_tok) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  if (i >= (long)n_tok * 32) return;
+  const int tok = (int)(i >> 5), c4 = (int)(i & 31);
+  float4 v = ((const float4*)x)[i];
+  if (hc) {
+    const float4 a = ((const float4*)(hc + (long)tok_seq[tok] * 128))[c4];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
+  ((float4*)xin)[i] = v;
+  const float4 p = ((const float4*)(pe + (long)tok_pos[tok] * 128))[c4];
+  ((float4*)h)[i] = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Attention, head_dim 16, 8 heads, sequences given by (start, len).  One wave per (sequence, head,
+// 16-query tile group); S^T = K Q^T with v_mfma_f32_16x16x16_bf16, so each lane owns one query
+// column; the S^T accumulator registers are, unchanged, the A operand of O = P V (row = query,
+// k = key), so P never leaves registers.  V is read as B operand (k = key, col = d).
+// qkv: [n_tok, 384] bf16 (q | k | v, heads contiguous inside each 128).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ seq_start,
+                                                            const int* __restrict__ seq_len, bf16_t* __restrict__ out,
+                                                            float scale_log2e) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int seq = blockIdx.x, head = blockIdx.y * 4 + wave;
+  const int s0 = seq_start[seq], len = seq_len[seq];
+  const int l15 = lane & 15, h4 = lane >> 4;
+  const int n_qt = (len + 15) >> 4, n_kt = n_qt;
+  const bf16_t* base = qkv + (long)s0 * 384 + head * 16;
+
+  for (int qt = 0; qt < n_qt; qt++) {
+    // B operand of S^T = K * Q^T:  B[k = d = 4*h4 + j][col = query l15]
+    int qrow = qt * 16 + l15;
+    qrow = qrow < len ? qrow : len - 1;
+    const bf16x4v qf = *(const bf16x4v*)(base + (long)qrow * 384 + 4 * h4);
+    float m_run = -1e30f, l_run = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};  // O tile: col = d (l15), rows = query 4*h4 + r
+    for (int kt0 = 0; kt0 < n_kt; kt0 += 10) {
+      const int nk = (n_kt - kt0) < 10 ? (n_kt - kt0) : 10;
+      f32x4 s[10];
+      bf16x4v vf[10];
+#pragma unroll
+      for (int t = 0; t < 10; t++) {
+        if (t < nk) {
+          const int kt = kt0 + t;
+          int krow = kt * 16 + l15;
+          krow = krow < len ? krow : len - 1;
+          // A operand: K[key l15][d = 4*h4 + j]
+          const bf16x4v kf = *(const bf16x4v*)(base + 128 + (long)krow * 384 + 4 * h4);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          // B operand of O = P V:  V[key = 4*h4 + j][d = l15]
+          bf16x4v v;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            int vr = kt * 16 + 4 * h4 + j;
+            vr = vr < len ? vr : len - 1;
+            v[j] = (short)base[256 + (long)vr * 384 + l15];
+          }
+          vf[t] = v;
+        }
+      }
+      // s[t][r] = score(query l15, key kt*16 + 4*h4 + r)
+      float mx = m_run;
+#pragma unroll
+      for (int t = 0; t < 10; t++)
+        if (t < nk) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int key = (kt0 + t) * 16 + 4 * h4 + r;
+            const float v = key < len ? s[t][r] * scale_log2e : -INFINITY;
+            s[t][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        }
+      mx = fmaxf(mx, lane_xor16(mx));
+      mx = fmaxf(mx, lane_xor32(mx));
+      const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
+      m_run = mx;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 10; t++)
+        if (t < nk) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pv = __builtin_amdgcn_exp2f(s[t][r] - mx);
+            s[t][r] = pv;
+            ps += pv;
+          }
+        }
+      l_run = l_run * alpha + ps;
+      // alpha belongs to query l15 but the O tile holds queries 4*h4 + r on its rows: fetch per row
+      float arow[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) arow[r] = __shfl(alpha, 4 * h4 + r, 64);
+#pragma unroll
+      for (int r = 0; r < 4; r++) o[r] *= arow[r];
+#pragma unroll
+      for (int t = 0; t < 10; t++)
+        if (t < nk) {
+          union { bf16x4v v; uint32_t u[2]; } pa;  // A operand: P[query l15][key 4*h4 + j]
+          pa.u[0] = pack_bf16x2(s[t][0], s[t][1]);
+          pa.u[1] = pack_bf16x2(s[t][2], s[t][3]);
+          o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa.v, vf[t], o, 0, 0, 0);
+        }
+    }
+    float lt = l_run + lane_xor16(l_run);
+    lt += lane_xor32(lt);
+    // rows of the O tile are queries 4*h4 + r: fetch their normalisers
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int q = qt * 16 + 4 * h4 + r;
+      const float inv = 1.0f / __shfl(lt, 4 * h4 + r, 64);
+      if (q < len) out[(long)(s0 + q) * 128 + head * 16 + l15] = f32_to_bf16(o[r] * inv);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Final LayerNorm (eps 1e-6) of the encoder stack + GlobalLayerNorm over (time, channel) of each
+// sequence + skip:  y = g_c * (LN(h) - mean) / sqrt(var + 1e-8) + b_c + xin.   One block/sequence,
+// two passes (LN recomputed, h stays in L2).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 ln_row128(const float* __restrict__ row, const float* __restrict__ g,
+                                            const float* __restrict__ b, int lane) {
+  const float2 v = ((const float2*)row)[lane];
+  const float mean = wave_reduce_sum(v.x + v.y) * (1.0f / 128.0f);
+  const float dx = v.x - mean, dy = v.y - mean;
+  const float rstd = rsqrtf(wave_reduce_sum(dx * dx + dy * dy) * (1.0f / 128.0f) + 1e-6f);
+  const float2 gg = ((const float2*)g)[lane], bb = ((const float2*)b)[lane];
+  return make_float2(dx * rstd * gg.x + bb.x, dy * rstd * gg.y + bb.y);
+}
+
+__global__ __launch_bounds__(256) void sep_final_norm_kernel(const float* __restrict__ h, const float* __restrict__ xin,
+                                                             const int* __restrict__ seq_start, const int* __restrict__ seq_len,
+                                                             const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                             const float* __restrict__ gln_g, const float* __restrict__ gln_b,
+                                                             float* __restrict__ y) {
+  __shared__ float red[8];
+  const int seq = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = seq_start[seq], len = seq_len[seq];
+  float sum = 0.f;
+  for (int r = wave; r < len; r += 4) {
+    const float2 v = ln_row128(h + (long)(s0 + r) * 128, ln_g, ln_b, lane);
+    sum += v.x + v.y;
+  }
+  sum = wave_reduce_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float n = (float)len * 128.0f;
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / n;
+  float sq = 0.f;
+  for (int r = wave; r < len; r += 4) {
+    const float2 v = ln_row128(h + (long)(s0 + r) * 128, ln_g, ln_b, lane);
+    sq += (v.x - mean) * (v.x - mean) + (v.y - mean) * (v.y - mean);
+  }
+  sq = wave_reduce_sum(sq);
+  if (lane == 0) red[4 + wave] = sq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / n + 1e-8f);
+  const float2 gg = ((const float2*)gln_g)[lane], bb = ((const float2*)gln_b)[lane];
+  for (int r = wave; r < len; r += 4) {
+    const float2 v = ln_row128(h + (long)(s0 + r) * 128, ln_g, ln_b, lane);
+    const float2 xi = ((const float2*)(xin + (long)(s0 + r) * 128))[lane];
+    ((float2*)(y + (long)(s0 + r) * 128))[lane] =
+        make_float2(gg.x * (v.x - mean) * rstd + bb.x + xi.x, gg.y * (v.y - mean) * rstd + bb.y + xi.y);
+  }
+}
+
+// chunk means: mem[chunk][:] = mean over the chunk's 150 tokens
+__global__ __launch_bounds__(128) void sep_chunk_mean_kernel(const float* __restrict__ x, float* __restrict__ mem, int seg) {
+  const int chunk = blockIdx.x, c = threadIdx.x;
+  const float* p = x + (long)chunk * seg * 128 + c;
+  float s = 0.f;
+  for (int t = 0; t < seg; t++) s += p[(long)t * 128];
+  mem[(long)chunk * 128 + c] = s / (float)seg;
+}
+
+// PReLU (single slope) -> bf16 (input of the output 1x1 conv GEMM)
+__global__ void sep_prelu_bf16_kernel(const float* __restrict__ x, const float* __restrict__ slope, bf16_t* __restrict__ out, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float a = slope[0];
+  const float4 v = ((const float4*)x)[i];
+  uint2 o;
+  o.x = pack_bf16x2(v.x >= 0 ? v.x : a * v.x, v.y >= 0 ? v.y : a * v.y);
+  o.y = pack_bf16x2(v.z >= 0 ? v.z : a * v.z, v.w >= 0 ? v.w : a * v.w);
+  ((uint2*)out)[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mask (ReLU) * encoder output, ConvTranspose1d(128 -> 1, k16, s8) overlap-add, pad/trim to T:
+//   est[u][t][spk] = sum_{l in {t/8, t/8-1}} sum_c feats[l][c] * relu(fc[l][2c+spk]) * wdec[c][t-8l]
+// One wave per output sample pair-of-speakers: lanes split the 128 channels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sep_decoder_kernel(const float* __restrict__ feats, const float* __restrict__ fc,
+                                                          const int* __restrict__ utt_tok0, const int* __restrict__ utt_L,
+                                                          const int* __restrict__ utt_T, const float* __restrict__ wdec,  // [128][16]
+                                                          float* __restrict__ out, long out_stride, int n_utt) {
+  const int u = blockIdx.y;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int T = utt_T[u], L = utt_L[u];
+  if (t >= T) return;
+  float a0 = 0.f, a1 = 0.f;
+  const int l_hi = t >> 3;
+#pragma unroll
+  for (int dl = 0; dl < 2; dl++) {
+    const int l = l_hi - dl, k = t - 8 * l;
+    if (l < 0 || l >= L || k >= 16) continue;
+    const long tok = utt_tok0[u] + l;
+    const float2 f = ((const float2*)(feats + tok * 128))[lane];          // channels 2*lane, 2*lane+1
+    const float4 m = ((const float4*)(fc + tok * 256))[lane];             // (c0,s0) (c0,s1) (c1,s0) (c1,s1)
+    const float w0 = wdec[(2 * lane) * 16 + k], w1 = wdec[(2 * lane + 1) * 16 + k];
+    a0 += f.x * fmaxf(m.x, 0.f) * w0 + f.y * fmaxf(m.z, 0.f) * w1;
+    a1 += f.x * fmaxf(m.y, 0.f) * w0 + f.y * fmaxf(m.w, 0.f) * w1;
+  }
+  a0 = wave_reduce_sum(a0);
+  a1 = wave_reduce_sum(a1);
+  if (lane == 0) ((float2*)(out + ((long)u * out_stride + t) * 2))[0] = make_float2(a0, a1);
+}
+
+struct HostT {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct SepLayer {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+  bf16_t *Wqkv, *Wo, *W1, *W2;
+};
+struct SepBlock {
+  std::vector<SepLayer> layers;
+  float *lnf_g, *lnf_b, *gln_g, *gln_b;
+};
+
+inline bf16_t h2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+}  // namespace
+
+struct ccx_sepformer {
+  ccx_ctx* ctx = nullptr;
+  ccx_sepformer_dims d{};
+  int max_tokens = 0, max_utts = 0;
+  bool finalized = false;
+  std::map<std::string, HostT> staged;
+  std::vector<void*> allocs;
+  float *w_enc = nullptr, *w_dec = nullptr, *prelu = nullptr, *b_fc = nullptr, *pe = nullptr;
+  bf16_t* W_fc = nullptr;
+  std::vector<SepBlock> seg, mem;
+  // workspaces
+  float *feats = nullptr, *x = nullptr, *xin = nullptr, *h = nullptr, *fc = nullptr, *memx = nullptr, *memxin = nullptr,
+        *memh = nullptr, *hc = nullptr;
+  bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
+  int *tok_utt = nullptr, *tok_pos = nullptr, *tok_chunk = nullptr, *tok_cpos = nullptr, *chunk_start = nullptr,
+      *chunk_len = nullptr, *utt_L = nullptr, *utt_T = nullptr, *utt_tok0 = nullptr, *utt_chunk0 = nullptr, *utt_nchunk = nullptr,
+      *mem_utt = nullptr, *mem_pos = nullptr;
+  int pe_len = 0;
+};
+
+namespace {
+
+#define STRY(expr)        \
+  do {                    \
+    int _rc = (expr);     \
+    if (_rc) return _rc;  \
+  } while (0)
+
+template <typename T>
+int salloc(ccx_sepformer* s, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = ccx_align(count * sizeof(T), 256);
+  CCX_HIP(s->ctx, hipMalloc(&p, bytes));
+  CCX_HIP(s->ctx, hipMemset(p, 0, bytes));
+  s->allocs.push_back(p);
+  *out = (T*)p;
+  return CCX_OK;
+}
+int sup_f32(ccx_sepformer* s, float** out, const float* src, size_t n) {
+  STRY(salloc(s, out, n));
+  CCX_HIP(s->ctx, hipMemcpy(*out, src, n * 4, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+int sup_bf16(ccx_sepformer* s, bf16_t** out, const float* src, size_t n) {
+  std::vector<bf16_t> tmp(n);
+  for (size_t i = 0; i < n; i++) tmp[i] = h2bf(src[i]);
+  STRY(salloc(s, out, n));
+  CCX_HIP(s->ctx, hipMemcpy(*out, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+int sneed(ccx_sepformer* s, const std::string& name, std::vector<int64_t> shape, const HostT** out) {
+  auto it = s->staged.find(name);
+  if (it == s->staged.end()) return ccx_fail(s->ctx, CCX_ERR_MISSING, "sepformer: tensor '%s' was never set", name.c_str());
+  size_t want = 1, got = it->second.data.size();
+  for (auto v : shape) want *= (size_t)v;
+  if (want != got) return ccx_fail(s->ctx, CCX_ERR_ARG, "sepformer: tensor '%s' has %zu elements, expected %zu", name.c_str(), got, want);
+  *out = &it->second;
+  return CCX_OK;
+}
+#define SNEED(var, name, ...)                                              \
+  const HostT* var = nullptr;                                              \
+  STRY(sneed(s, (name), std::vector<int64_t>{__VA_ARGS__}, &var));
+
+int load_block(ccx_sepformer* s, const std::string& prefix, SepBlock& B) {
+  const int D = s->d.d_model, F = s->d.d_ffn;
+  B.layers.resize(s->d.n_layers);
+  for (int l = 0; l < s->d.n_layers; l++) {
+    const std::string p = prefix + ".mdl.layers." + std::to_string(l);
+    SepLayer& L = B.layers[l];
+    SNEED(wi, p + ".self_att.att.in_proj_weight", 3 * D, D); SNEED(bi, p + ".self_att.att.in_proj_bias", 3 * D);
+    SNEED(wo, p + ".self_att.att.out_proj.weight", D, D); SNEED(bo, p + ".self_att.att.out_proj.bias", D);
+    SNEED(w1, p + ".pos_ffn.ffn.0.weight", F, D); SNEED(b1, p + ".pos_ffn.ffn.0.bias", F);
+    SNEED(w2, p + ".pos_ffn.ffn.3.weight", D, F); SNEED(b2, p + ".pos_ffn.ffn.3.bias", D);
+    SNEED(g1, p + ".norm1.norm.weight", D); SNEED(be1, p + ".norm1.norm.bias", D);
+    SNEED(g2, p + ".norm2.norm.weight", D); SNEED(be2, p + ".norm2.norm.bias", D);
+    STRY(sup_bf16(s, &L.Wqkv, wi->data.data(), wi->data.size())); STRY(sup_f32(s, &L.bqkv, bi->data.data(), 3 * D));
+    STRY(sup_bf16(s, &L.Wo, wo->data.data(), wo->data.size())); STRY(sup_f32(s, &L.bo, bo->data.data(), D));
+    STRY(sup_bf16(s, &L.W1, w1->data.data(), w1->data.size())); STRY(sup_f32(s, &L.b1, b1->data.data(), F));
+    STRY(sup_bf16(s, &L.W2, w2->data.data(), w2->data.size())); STRY(sup_f32(s, &L.b2, b2->data.data(), D));
+    STRY(sup_f32(s, &L.ln1_g, g1->data.data(), D)); STRY(sup_f32(s, &L.ln1_b, be1->data.data(), D));
+    STRY(sup_f32(s, &L.ln2_g, g2->data.data(), D)); STRY(sup_f32(s, &L.ln2_b, be2->data.data(), D));
+  }
+  SNEED(fg, prefix + ".mdl.norm.norm.weight", D); SNEED(fb, prefix + ".mdl.norm.norm.bias", D);
+  SNEED(gg, prefix + ".norm.weight", D); SNEED(gb, prefix + ".norm.bias", D);
+  STRY(sup_f32(s, &B.lnf_g, fg->data.data(), D)); STRY(sup_f32(s, &B.lnf_b, fb->data.data(), D));
+  STRY(sup_f32(s, &B.gln_g, gg->data.data(), D)); STRY(sup_f32(s, &B.gln_b, gb->data.data(), D));
+  return CCX_OK;
+}
+
+// One SBTransformerBlock_wnormandskip over `n_tok` tokens organised in `n_seq` sequences.
+int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* hc, const int* tok_seq, const int* tok_pos,
+              const int* seq_start, const int* seq_len, int n_tok, int n_seq, float* xin, float* h, float* y, hipStream_t st) {
+  ccx_ctx* ctx = s->ctx;
+  const int D = s->d.d_model, F = s->d.d_ffn;
+  hipLaunchKernelGGL(sep_block_input_kernel, dim3(ccx_cdiv(n_tok * 32, 256)), dim3(256), 0, st, x, hc, tok_seq, tok_pos, s->pe,
+                     xin, h, n_tok);
+  CCX_CHECK_LAUNCH(ctx);
+  const float scale_log2e = 0.25f * 1.4426950408889634f;  // 1/sqrt(16)
+  for (const SepLayer& L : B.layers) {
+    GemmParams p;
+    STRY(ccx_launch_layernorm(ctx, h, D, L.ln1_g, L.ln1_b, s->xn, nullptr, D, n_tok, D, 1e-6f, st));
+    memset(&p, 0, sizeof(p));
+    p.A = s->xn; p.lda = D; p.W = L.Wqkv; p.ldw = D; p.M = n_tok; p.N = 3 * D; p.K = D; p.bias = L.bqkv; p.out = s->qkv; p.ldo = 3 * D;
+    STRY(ccx_launch_gemm(ctx, EPI_BF16, p, st));
+    {
+      ccx_prof_scope ps(ctx, st, "sep_attention_kernel", 0.0, 0.0);
+      hipLaunchKernelGGL(sep_attention_kernel, dim3(n_seq, s->d.n_head / 4), dim3(256), 0, st, s->qkv, seq_start, seq_len, s->att,
+                         scale_log2e);
+    }
+    CCX_CHECK_LAUNCH(ctx);
+    memset(&p, 0, sizeof(p));
+    p.A = s->att; p.lda = D; p.W = L.Wo; p.ldw = D; p.M = n_tok; p.N = D; p.K = D; p.bias = L.bo; p.out = h; p.ldo = D; p.resid = h; p.ldr = D;
+    STRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st));
+    STRY(ccx_launch_layernorm(ctx, h, D, L.ln2_g, L.ln2_b, s->xn, nullptr, D, n_tok, D, 1e-6f, st));
+    memset(&p, 0, sizeof(p));
+    p.A = s->xn; p.lda = D; p.W = L.W1; p.ldw = D; p.M = n_tok; p.N = F; p.K = D; p.bias = L.b1; p.out = s->ffn; p.ldo = F;
+    STRY(ccx_launch_gemm(ctx, EPI_BF16_RELU, p, st));
+    memset(&p, 0, sizeof(p));
+    p.A = s->ffn; p.lda = F; p.W = L.W2; p.ldw = F; p.M = n_tok; p.N = D; p.K = F; p.bias = L.b2; p.out = h; p.ldo = D; p.resid = h; p.ldr = D;
+    STRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st));
+  }
+  hipLaunchKernelGGL(sep_final_norm_kernel, dim3(n_seq), dim3(256), 0, st, h, xin, seq_start, seq_len, B.lnf_g, B.lnf_b, B.gln_g,
+                     B.gln_b, y);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccx_sepformer_create(ccx_ctx* ctx, const ccx_sepformer_dims* dims, int max_tokens, int max_utts, ccx_sepformer** out) {
+  if (!ctx) return CCX_ERR_ARG;
+  CCX_REQUIRE(ctx, dims && out, "ccx_sepformer_create: null argument");
+  const ccx_sepformer_dims& d = *dims;
+  CCX_REQUIRE(ctx, d.n_filters == 128 && d.d_model == 128 && d.kernel == 16 && d.stride == 8 && d.n_head == 8 && d.n_spk == 2,
+              "sepformer: only the resepformer-wsj02mix geometry (128 filters, k16 s8, d_model 128, 8 heads, 2 speakers) is built");
+  CCX_REQUIRE(ctx, d.d_ffn % 128 == 0 && d.segment >= 16 && d.n_layers >= 1 && d.n_blocks >= 1, "sepformer: bad dims");
+  CCX_REQUIRE(ctx, max_tokens >= d.segment && max_utts >= 1, "sepformer: capacity too small");
+  ccx_sepformer* s = new ccx_sepformer();
+  s->ctx = ctx; s->d = d;
+  s->max_tokens = ccx_cdiv(max_tokens, d.segment) * d.segment;
+  s->max_utts = max_utts;
+  *out = s;
+  return CCX_OK;
+}
+
+void ccx_sepformer_destroy(ccx_sepformer* s) {
+  if (!s) return;
+  for (void* p : s->allocs) hipFree(p);
+  delete s;
+}
+
+int ccx_sepformer_set_tensor(ccx_sepformer* s, const char* name, const float* data, int64_t numel) {
+  if (!s) return CCX_ERR_ARG;
+  CCX_REQUIRE(s->ctx, !s->finalized && name && data && numel > 0, "sepformer: set_tensor bad arguments");
+  const std::string nm(name);
+  CCX_REQUIRE(s->ctx, nm.rfind("encoder.", 0) == 0 || nm.rfind("decoder.", 0) == 0 || nm.rfind("masknet.", 0) == 0,
+              "sepformer: unknown tensor name '%s'", name);
+  HostT t;
+  t.data.resize((size_t)numel);
+  CCX_HIP(s->ctx, hipMemcpy(t.data.data(), data, (size_t)numel * 4, hipMemcpyDefault));
+  s->staged[nm] = std::move(t);
+  return CCX_OK;
+}
+
+int ccx_sepformer_finalize(ccx_sepformer* s) {
+  if (!s) return CCX_ERR_ARG;
+  CCX_REQUIRE(s->ctx, !s->finalized, "sepformer: finalize called twice");
+  const ccx_sepformer_dims& d = s->d;
+  const int D = d.d_model, F = d.d_ffn, N = d.n_filters;
+  {
+    SNEED(we, "encoder.conv1d.weight", N, 1, d.kernel);
+    SNEED(wd, "decoder.weight", N, 1, d.kernel);
+    SNEED(pr, "masknet.model.output_fc.0.weight", 1);
+    SNEED(wf, "masknet.model.output_fc.1.weight", N * d.n_spk, D, 1);
+    SNEED(bf, "masknet.model.output_fc.1.bias", N * d.n_spk);
+    STRY(sup_f32(s, &s->w_enc, we->data.data(), we->data.size()));
+    STRY(sup_f32(s, &s->w_dec, wd->data.data(), wd->data.size()));
+    STRY(sup_f32(s, &s->prelu, pr->data.data(), 1));
+    STRY(sup_bf16(s, &s->W_fc, wf->data.data(), wf->data.size()));
+    STRY(sup_f32(s, &s->b_fc, bf->data.data(), bf->data.size()));
+  }
+  s->seg.resize(d.n_blocks);
+  s->mem.resize(d.n_blocks > 0 ? d.n_blocks - 1 : 0);
+  for (int i = 0; i < d.n_blocks; i++) {
+    STRY(load_block(s, "masknet.model.seg_model." + std::to_string(i), s->seg[i]));
+    if (i < d.n_blocks - 1) STRY(load_block(s, "masknet.model.mem_model." + std::to_string(i), s->mem[i]));
+  }
+  s->staged.clear();
+  // positional encoding table (interleaved sin/cos), long enough for a chunk and for the longest memory sequence
+  const int max_chunks = s->max_tokens / d.segment;
+  s->pe_len = d.segment > max_chunks ? d.segment : max_chunks;
+  {
+    std::vector<float> pe((size_t)s->pe_len * D);
+    for (int p = 0; p < s->pe_len; p++)
+      for (int i = 0; i < D; i += 2) {
+        const float den = expf((float)i * -(logf(10000.0f) / (float)D));
+        pe[(size_t)p * D + i] = sinf((float)p * den);
+        pe[(size_t)p * D + i + 1] = cosf((float)p * den);
+      }
+    STRY(sup_f32(s, &s->pe, pe.data(), pe.size()));
+  }
+  const size_t T = (size_t)s->max_tokens;
+  STRY(salloc(s, &s->feats, T * D)); STRY(salloc(s, &s->x, T * D)); STRY(salloc(s, &s->xin, T * D)); STRY(salloc(s, &s->h, T * D));
+  STRY(salloc(s, &s->fc, T * 2 * D)); STRY(salloc(s, &s->xn, T * D)); STRY(salloc(s, &s->qkv, T * 3 * D));
+  STRY(salloc(s, &s->att, T * D)); STRY(salloc(s, &s->ffn, T * F));
+  STRY(salloc(s, &s->memx, (size_t)max_chunks * D)); STRY(salloc(s, &s->memxin, (size_t)max_chunks * D));
+  STRY(salloc(s, &s->memh, (size_t)max_chunks * D)); STRY(salloc(s, &s->hc, (size_t)max_chunks * D));
+  STRY(salloc(s, &s->tok_utt, T)); STRY(salloc(s, &s->tok_pos, T)); STRY(salloc(s, &s->tok_chunk, T)); STRY(salloc(s, &s->tok_cpos, T));
+  STRY(salloc(s, &s->chunk_start, (size_t)max_chunks)); STRY(salloc(s, &s->chunk_len, (size_t)max_chunks));
+  STRY(salloc(s, &s->mem_utt, (size_t)max_chunks)); STRY(salloc(s, &s->mem_pos, (size_t)max_chunks));
+  const size_t U = (size_t)s->max_utts;
+  STRY(salloc(s, &s->utt_L, U)); STRY(salloc(s, &s->utt_T, U)); STRY(salloc(s, &s->utt_tok0, U)); STRY(salloc(s, &s->utt_chunk0, U));
+  STRY(salloc(s, &s->utt_nchunk, U));
+  s->finalized = true;
+  return CCX_OK;
+}
+
+int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, const int* n_samples, int B, float* out,
+                           void* stream_) {
+  if (!s) return CCX_ERR_ARG;
+  ccx_ctx* ctx = s->ctx;
+  hipStream_t st = (hipStream_t)stream_;
+  CCX_REQUIRE(ctx, s->finalized && mix && n_samples && out && B >= 1 && B <= s->max_utts, "sepformer_separate: bad arguments (B=%d, max %d)", B, s->max_utts);
+  const ccx_sepformer_dims& d = s->d;
+  const int D = d.d_model, seg = d.segment;
+  // ---- host-side ragged bookkeeping (tiny) ----
+  std::vector<int> uL(B), uT(B), utok0(B), uchunk0(B), unchunk(B);
+  int n_tok = 0, n_chunk = 0;
+  for (int b = 0; b < B; b++) {
+    CCX_REQUIRE(ctx, n_samples[b] >= d.kernel && n_samples[b] <= stride, "sepformer_separate: utterance %d has %d samples (need >= %d, <= stride)", b, n_samples[b], d.kernel);
+    uT[b] = n_samples[b];
+    uL[b] = (n_samples[b] - d.kernel) / d.stride + 1;
+    const int rest = seg - uL[b] % seg;  // a full extra chunk when L % seg == 0, as _padfeature does
+    unchunk[b] = (uL[b] + rest) / seg;
+    utok0[b] = n_tok; uchunk0[b] = n_chunk;
+    n_tok += unchunk[b] * seg; n_chunk += unchunk[b];
+  }
+  CCX_REQUIRE(ctx, n_tok <= s->max_tokens, "sepformer_separate: %d tokens exceed capacity %d", n_tok, s->max_tokens);
+  CCX_REQUIRE(ctx, n_chunk <= s->pe_len, "sepformer_separate: memory sequence too long");
+  std::vector<int> t_utt(n_tok), t_pos(n_tok), t_chunk(n_tok), t_cpos(n_tok), c_start(n_chunk), c_len(n_chunk), m_utt(n_chunk), m_pos(n_chunk);
+  for (int b = 0; b < B; b++) {
+    for (int c = 0; c < unchunk[b]; c++) {
+      const int cg = uchunk0[b] + c;
+      c_start[cg] = utok0[b] + c * seg; c_len[cg] = seg; m_utt[cg] = b; m_pos[cg] = c;
+      for (int i = 0; i < seg; i++) {
+        const int t = c_start[cg] + i;
+        t_utt[t] = b; t_pos[t] = c * seg + i; t_chunk[t] = cg; t_cpos[t] = i;
+      }
+    }
+  }
+#define UP(dst, vec) CCX_HIP(ctx, hipMemcpyAsync(dst, vec.data(), vec.size() * 4, hipMemcpyHostToDevice, st))
+  UP(s->tok_utt, t_utt); UP(s->tok_pos, t_pos); UP(s->tok_chunk, t_chunk); UP(s->tok_cpos, t_cpos);
+  UP(s->chunk_start, c_start); UP(s->chunk_len, c_len); UP(s->mem_utt, m_utt); UP(s->mem_pos, m_pos);
+  UP(s->utt_L, uL); UP(s->utt_T, uT); UP(s->utt_tok0, utok0); UP(s->utt_chunk0, uchunk0); UP(s->utt_nchunk, unchunk);
+#undef UP
+  CCX_HIP(ctx, hipStreamSynchronize(st));  // host staging vectors go out of scope
+
+  hipLaunchKernelGGL(sep_encoder_kernel, dim3(ccx_cdiv(n_tok, 4)), dim3(256), 0, st, mix, (long)stride, s->tok_utt, s->tok_pos,
+                     s->utt_L, s->w_enc, s->feats, n_tok);
+  CCX_CHECK_LAUNCH(ctx);
+  const float* cur = s->feats;
+  const float* hc = nullptr;
+  for (int i = 0; i < d.n_blocks; i++) {
+    STRY(run_block(s, s->seg[i], cur, hc, s->tok_chunk, s->tok_cpos, s->chunk_start, s->chunk_len, n_tok, n_chunk, s->xin, s->h,
+                   s->x, st));
+    cur = s->x;
+    if (i < d.n_blocks - 1) {
+      hipLaunchKernelGGL(sep_chunk_mean_kernel, dim3(n_chunk), dim3(128), 0, st, s->x, s->memx, seg);
+      CCX_CHECK_LAUNCH(ctx);
+      // memory transformer: one sequence per utterance over its chunk means
+      STRY(run_block(s, s->mem[i], s->memx, nullptr, s->mem_utt, s->mem_pos, s->utt_chunk0, s->utt_nchunk, n_chunk, B, s->memxin,
+                     s->memh, s->hc, st));
+      hc = s->hc;
+    }
+  }
+  hipLaunchKernelGGL(sep_prelu_bf16_kernel, dim3(ccx_cdiv(n_tok * 32, 256)), dim3(256), 0, st, s->x, s->prelu, s->xn, (long)n_tok * 32);
+  CCX_CHECK_LAUNCH(ctx);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = s->xn; p.lda = D; p.W = s->W_fc; p.ldw = D; p.M = n_tok; p.N = 2 * D; p.K = D; p.bias = s->b_fc; p.out = s->fc; p.ldo = 2 * D;
+  STRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+  CCX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)B * stride * 2 * 4, st));
+  hipLaunchKernelGGL(sep_decoder_kernel, dim3(ccx_cdiv((int)stride, 4), B), dim3(256), 0, st, s->feats, s->fc, s->utt_tok0, s->utt_L,
+                     s->utt_T, s->w_dec, out, (long)stride, B);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+}  // extern "C"

@@ -119,3 +119,59 @@ def find_whisper_checkpoint(model_size: str = "small.en", cache_dir: Optional[st
         over = torch.load(pt_path, map_location="cpu", weights_only=True)
         sd.update({k: v.float() for k, v in over.items() if k in sd})
     return dims, sd
+
+
+# ----------------------------------------------------------------------------------------------
+# RE-SepFormer (speechbrain/resepformer-wsj02mix hyper-parameters [UPSTREAM-RECALL])
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class SepDims:
+    n_filters: int = 128
+    kernel: int = 16
+    stride: int = 8
+    d_model: int = 128
+    n_head: int = 8
+    d_ffn: int = 1024
+    n_layers: int = 8
+    n_blocks: int = 2
+    segment: int = 150
+    n_spk: int = 2
+
+
+def synthetic_sepformer_state_dict(dims: SepDims, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded weights in the SpeechBrain checkpoint key layout (`encoder.ckpt`, `masknet.ckpt`,
+    `decoder.ckpt` of the reference's overlay, back/api.py:729-746, each prefixed with its module
+    name).  Fan-in scaled so every sub-layer contributes."""
+    g = torch.Generator().manual_seed(seed)
+    D, Fd = dims.d_model, dims.d_ffn
+    sd: Dict[str, torch.Tensor] = {}
+    sd["encoder.conv1d.weight"] = torch.randn(dims.n_filters, 1, dims.kernel, generator=g) / math.sqrt(dims.kernel) * 2.0
+    sd["decoder.weight"] = torch.randn(dims.n_filters, 1, dims.kernel, generator=g) / math.sqrt(dims.n_filters)
+
+    def block(prefix):
+        for l in range(dims.n_layers):
+            p = f"{prefix}.mdl.layers.{l}"
+            sd[p + ".self_att.att.in_proj_weight"] = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+            sd[p + ".self_att.att.in_proj_bias"] = 0.1 * torch.randn(3 * D, generator=g)
+            sd[p + ".self_att.att.out_proj.weight"] = torch.randn(D, D, generator=g) / math.sqrt(D)
+            sd[p + ".self_att.att.out_proj.bias"] = 0.1 * torch.randn(D, generator=g)
+            sd[p + ".pos_ffn.ffn.0.weight"] = torch.randn(Fd, D, generator=g) / math.sqrt(D)
+            sd[p + ".pos_ffn.ffn.0.bias"] = 0.1 * torch.randn(Fd, generator=g)
+            sd[p + ".pos_ffn.ffn.3.weight"] = torch.randn(D, Fd, generator=g) / math.sqrt(Fd)
+            sd[p + ".pos_ffn.ffn.3.bias"] = 0.1 * torch.randn(D, generator=g)
+            for nm in ("norm1", "norm2"):
+                sd[f"{p}.{nm}.norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+                sd[f"{p}.{nm}.norm.bias"] = 0.1 * torch.randn(D, generator=g)
+        sd[prefix + ".mdl.norm.norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+        sd[prefix + ".mdl.norm.norm.bias"] = 0.1 * torch.randn(D, generator=g)
+        sd[prefix + ".norm.weight"] = (1 + 0.1 * torch.randn(D, generator=g)).view(D, 1)
+        sd[prefix + ".norm.bias"] = (0.1 * torch.randn(D, generator=g)).view(D, 1)
+
+    for i in range(dims.n_blocks):
+        block(f"masknet.model.seg_model.{i}")
+        if i < dims.n_blocks - 1:
+            block(f"masknet.model.mem_model.{i}")
+    sd["masknet.model.output_fc.0.weight"] = torch.tensor([0.25])
+    sd["masknet.model.output_fc.1.weight"] = torch.randn(dims.n_filters * dims.n_spk, D, 1, generator=g) / math.sqrt(D)
+    sd["masknet.model.output_fc.1.bias"] = 0.1 * torch.randn(dims.n_filters * dims.n_spk, generator=g)
+    return sd

@@ -112,6 +112,28 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
                               int32_t* n_tokens_out, float* sum_logprob_out, float* no_speech_prob_out,
                               void* stream);
 
+/* ---- RE-SepFormer separator (replaces self.separator, reference back/api.py:713-717; call at
+ *      back/api.py:1077 `separated = self.separator.separate_batch(subsegment)`) -------------------- */
+
+typedef struct ccx_sepformer ccx_sepformer;
+typedef struct {
+  int n_filters, kernel, stride, d_model, n_head, d_ffn, n_layers, n_blocks, segment, n_spk;
+} ccx_sepformer_dims;
+
+/* max_tokens: capacity in encoder frames summed over the utterances of one call (each padded to
+ * whole `segment`-frame chunks); max_utts: utterances per call. */
+int ccx_sepformer_create(ccx_ctx* ctx, const ccx_sepformer_dims* dims, int max_tokens, int max_utts,
+                         ccx_sepformer** out);
+void ccx_sepformer_destroy(ccx_sepformer* s);
+/* Tensors by SpeechBrain checkpoint key, prefixed with the module name of the reference's overlay
+ * files (back/api.py:729): "encoder.conv1d.weight", "decoder.weight", "masknet.model....". f32. */
+int ccx_sepformer_set_tensor(ccx_sepformer* s, const char* name, const float* data, int64_t numel);
+int ccx_sepformer_finalize(ccx_sepformer* s);
+/* separate_batch for B independent utterances: mix_dev [B, stride] f32, n_samples host [B] ->
+ * out_dev [B, stride, 2] f32 (rows past n_samples[b] are zero). */
+int ccx_sepformer_separate(ccx_sepformer* s, const float* mix_dev, int64_t stride, const int* n_samples, int B,
+                           float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
