@@ -69,6 +69,12 @@ PROTOTYPES = {
     "ccx_sepformer_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i64]),
     "ccx_sepformer_finalize": (_i, [_vp]),
     "ccx_sepformer_separate": (_i, [_vp, _vp, _i64, _ip, _i, _vp, _vp]),
+    "ccx_speaker_create": (_i, [_vp, _i, _i, _i, _i, _i64, C.POINTER(_vp)]),
+    "ccx_speaker_destroy": (None, [_vp]),
+    "ccx_speaker_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i64]),
+    "ccx_speaker_finalize": (_i, [_vp]),
+    "ccx_speaker_embed": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _vp]),
+    "ccx_speaker_segment": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64, _ip, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -11,7 +11,8 @@ enum GemmEpi {
   EPI_F32 = 3,         // out f32  = acc + bias
   EPI_HEADS = 4,       // q/k (/v) scattered head-major for the attention kernels
   EPI_BF16_RELU = 5,   // out bf16 = relu(acc + bias)
-  EPI_F32_GELU_POS = 6 // out f32 = gelu(acc + bias) + resid[row % resid_mod][n]   (conv2 + pos-emb)
+  EPI_F32_GELU_POS = 6, // out f32 = gelu(acc + bias) + resid[row % resid_mod][n]   (conv2 + pos-emb)
+  EPI_BF16_LRELU_AFFINE = 7 // out bf16 = leaky_relu(acc + bias (+ resid)) * scale[n] + shift[n]  (TDNN conv + BatchNorm)
 };
 
 struct GemmParams {
@@ -25,6 +26,8 @@ struct GemmParams {
   const float* resid; // f32
   long ldr;
   int resid_mod;     // if > 0: resid row = out_row % resid_mod
+  const float* scale; const float* shift;  // EPI_BF16_LRELU_AFFINE: per-column affine after the activation (may be null)
+  float slope;       // LeakyReLU negative slope
   // output row remap: rows arrive in groups of rpb_in; group g row i -> g*rpb_out + i + roff,
   // rows with i >= rpb_valid are dropped.  rpb_in == 0 -> identity.
   int rpb_in, rpb_out, roff, rpb_valid;

@@ -198,7 +198,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     const long orow = remap_row(p, m, valid);
     if (!valid) continue;
 
-    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU) {
+    if (EPI == EPI_BF16_LRELU_AFFINE) {
+      if (p.resid) {
+        const float4* rp = (const float4*)(p.resid + orow * p.ldr + nb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float4 r4 = rp[i];
+          v[4 * i + 0] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
+        const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
+        const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
+        v[i] = t * sc + sh;
+      }
+    }
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE) {
       if (EPI == EPI_BF16_GELU) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
@@ -247,7 +264,7 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   }
   {
     // algorithmic work: 2*M*N*K flops; bytes = A + W read once + output written once
-    const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;
+    const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;  // output element size
     ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * p.K,
                       2.0 * ((double)p.M * p.K + (double)p.N * p.K) + obytes * p.M * (double)p.N);
     hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
@@ -277,6 +294,7 @@ int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stre
     case EPI_F32: return launch_epi<EPI_F32>(ctx, p, stream);
     case EPI_HEADS: return launch_epi<EPI_HEADS>(ctx, p, stream);
     case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(ctx, p, stream);
+    case EPI_BF16_LRELU_AFFINE: return launch_epi<EPI_BF16_LRELU_AFFINE>(ctx, p, stream);
   }
   return ccx_fail(ctx, CCX_ERR_ARG, "gemm: unknown epilogue %d", epi);
 }

@@ -1,0 +1,612 @@
+// speaker.hip -- pyannote-style speaker networks of libccx (K18-K20 in SURVEY.md section 2a):
+//   * SincNet front end (instance-norm'd waveform -> 80 sinc band-pass filters k251 s10 -> |.| ->
+//     maxpool3 -> instance norm -> leaky ReLU -> conv k5 -> pool -> IN -> conv k5 -> pool -> IN)
+//   * XVectorSincNet embedder (`pyannote/embedding`, reference back/api.py:776-780, called at 869):
+//     5 TDNN layers (dilated Conv1d + LeakyReLU + BatchNorm) -> mean||std pooling -> Linear(3000,512)
+//   * PyanNet segmentation net (inside the VAD / diarization pipelines, reference back/api.py:782-792):
+//     SincNet -> 4 x BiLSTM(128) -> 2 x Linear+LeakyReLU -> classifier -> log-softmax / sigmoid
+// Semantics follow pyannote.audio 3.x [UPSTREAM-RECALL]; CPU restatement: oracle/pyannote_ref.py.
+//
+// Batching: a call processes n crops of arbitrary lengths.  Every stage keeps the crops concatenated
+// as rows of one channel-last matrix, so each valid (un-padded) convolution is ONE bf16 MFMA GEMM over
+// all crops: a k-tap conv over channel-last rows is a GEMM whose A matrix is a strided VIEW of the
+// activations (row m = k consecutive frames, lda = channels), dilated taps are accumulated GEMMs.
+// Rows whose window crosses a crop end compute garbage that later stages never read.
+#include <map>
+#include <math.h>
+#include "../../include/ccx.h"
+#include "ccx_common.h"
+#include "gemm_bf16.h"
+
+namespace {
+
+#define SN_K 251
+#define SN_STRIDE 10
+#define SN_F 80
+
+// per-crop mean / rstd of the raw waveform (InstanceNorm1d(1, affine) -> a*x + c folded into the sinc conv)
+__global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict__ wav, const long* __restrict__ crop_off,
+                                                        const int* __restrict__ crop_len, const float* __restrict__ nw,
+                                                        const float* __restrict__ nb, float2* __restrict__ ac) {
+  __shared__ float red[8];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* x = wav + crop_off[i];
+  const int n = crop_len[i];
+  float s = 0.f;
+  for (int t = tid; t < n; t += 256) s += x[t];
+  s = wave_reduce_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+  float q = 0.f;
+  for (int t = tid; t < n; t += 256) { const float d = x[t] - mean; q += d * d; }
+  q = wave_reduce_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  if (tid == 0) {
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)n;
+    const float a = nw[0] * rsqrtf(var + 1e-5f);
+    ac[i] = make_float2(a, nb[0] - mean * a);
+  }
+}
+
+// Sinc conv (fp32, LDS-staged samples) + abs + maxpool3.  Block = one crop x 32 pooled frames
+// (96 conv frames, 1201 samples in LDS); 320 threads = 80 filters x 4 frame groups (8 pooled frames each).
+// out: [rows][80] f32 pooled |conv|.
+__global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __restrict__ wav, const long* __restrict__ crop_off,
+                                                             const int* __restrict__ crop_len, const int* __restrict__ row_off,
+                                                             const int* __restrict__ n_pool, const float2* __restrict__ ac,
+                                                             const float* __restrict__ filt_t,   // [251][80]
+                                                             const float* __restrict__ filt_sum, // [80]
+                                                             float* __restrict__ out) {
+  __shared__ float xs[96 * SN_STRIDE + SN_K + 3];
+  const int crop = blockIdx.y, p0 = blockIdx.x * 32;
+  const int np = n_pool[crop];
+  if (p0 >= np) return;
+  const float* x = wav + crop_off[crop];
+  const int n = crop_len[crop];
+  const int s0 = p0 * 3 * SN_STRIDE;
+  for (int i = threadIdx.x; i < 96 * SN_STRIDE + SN_K; i += 320) xs[i] = (s0 + i < n) ? x[s0 + i] : 0.f;
+  __syncthreads();
+  const int f = threadIdx.x % SN_F, grp = threadIdx.x / SN_F;   // grp 0..3 -> pooled frames p0 + 8*grp .. +8
+  float acc[24];
+#pragma unroll
+  for (int j = 0; j < 24; j++) acc[j] = 0.f;
+  const float* xb = xs + grp * 24 * SN_STRIDE;
+  for (int k = 0; k < SN_K; k++) {
+    const float w = filt_t[k * SN_F + f];
+#pragma unroll
+    for (int j = 0; j < 24; j++) acc[j] = fmaf(w, xb[j * SN_STRIDE + k], acc[j]);
+  }
+  const float2 a_c = ac[crop];
+  const float cs = a_c.y * filt_sum[f];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int p = p0 + 8 * grp + j;
+    if (p < np) {
+      const float v0 = fabsf(a_c.x * acc[3 * j] + cs), v1 = fabsf(a_c.x * acc[3 * j + 1] + cs), v2 = fabsf(a_c.x * acc[3 * j + 2] + cs);
+      out[((long)row_off[crop] + p) * SN_F + f] = fmaxf(v0, fmaxf(v1, v2));
+    }
+  }
+}
+
+// (optional maxpool3 over rows) + InstanceNorm over the crop's frames per channel + LeakyReLU -> bf16.
+// in: f32 rows [.., ld_in] at in_off[crop]; out: bf16 [.., ld_out] at out_off[crop], n_out[crop] frames,
+// channels >= C written as zeros.  Block = one crop, 256 threads = 64 channels x 4 frame groups.
+template <int POOL>
+__global__ __launch_bounds__(256) void pool_inorm_lrelu_kernel(const float* __restrict__ in, int ld_in, const int* __restrict__ in_off,
+                                                               bf16_t* __restrict__ out, int ld_out, const int* __restrict__ out_off,
+                                                               const int* __restrict__ n_out, const float* __restrict__ g,
+                                                               const float* __restrict__ b, int C) {
+  __shared__ float red[2][4][64];
+  const int crop = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int n = n_out[crop];
+  const float* x = in + (long)in_off[crop] * ld_in;
+  const bool live = c < C;
+  auto val = [&](int t) -> float {
+    if (POOL == 1) return x[(long)t * ld_in + c];
+    const float* p = x + (long)(3 * t) * ld_in + c;
+    return fmaxf(p[0], fmaxf(p[ld_in], p[2 * ld_in]));
+  };
+  float s = 0.f;
+  if (live) for (int t = grp; t < n; t += 4) s += val(t);
+  red[0][grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  const int cl = threadIdx.x & 63;
+  const float mean = (red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]) / (float)n;
+  float q = 0.f;
+  if (live) for (int t = grp; t < n; t += 4) { const float d = val(t) - mean; q += d * d; }
+  red[1][grp][cl] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]) / (float)n + 1e-5f);
+  bf16_t* o = out + (long)out_off[crop] * ld_out;
+  if (c < ld_out) {
+    const float gg = live ? g[c] : 0.f, bb = live ? b[c] : 0.f;
+    for (int t = grp; t < n; t += 4) {
+      float v = 0.f;
+      if (live) {
+        v = (val(t) - mean) * rstd * gg + bb;
+        v = v >= 0.f ? v : 0.01f * v;
+      }
+      o[(long)t * ld_out + c] = f32_to_bf16(v);
+    }
+  }
+}
+
+// mean || unbiased std over the crop's valid frames -> bf16 [n][ld] (mean at [0,C), std at [C,2C), zero pad)
+__global__ __launch_bounds__(256) void stats_pool_kernel(const bf16_t* __restrict__ x, int ld_in, const int* __restrict__ row_off,
+                                                         const int* __restrict__ n_valid, bf16_t* __restrict__ out, int ld_out, int C) {
+  const int crop = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int n = n_valid[crop];
+  const bf16_t* p = x + (long)row_off[crop] * ld_in + c;
+  float s = 0.f;
+  for (int t = 0; t < n; t++) s += bf16_to_f32(p[(long)t * ld_in]);
+  const float mean = s / (float)n;
+  float q = 0.f;
+  for (int t = 0; t < n; t++) { const float d = bf16_to_f32(p[(long)t * ld_in]) - mean; q += d * d; }
+  const float sd = sqrtf(q / (float)(n - 1));
+  out[(long)crop * ld_out + c] = f32_to_bf16(mean);
+  out[(long)crop * ld_out + C + c] = f32_to_bf16(sd);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM recurrence.  grid (crop, direction); 512 threads = the 512 gate rows (i|f|g|o x 128), each
+// keeping its W_hh row (128 f32) in registers; h lives in LDS and is broadcast-read as float4.
+// gx: [rows][1024] f32 = x W_ih^T + b_ih + b_hh (fwd 0..511 | rev 512..1023) from the MFMA GEMM.
+// hout: [rows][256] bf16 (fwd h | rev h).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __restrict__ gx, const float* __restrict__ whh,  // [2][512][128]
+                                                             const int* __restrict__ row_off, const int* __restrict__ n_rows,
+                                                             bf16_t* __restrict__ hout) {
+  __shared__ __attribute__((aligned(16))) float hs[128];
+  __shared__ float gate[512];
+  const int crop = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+  const int n = n_rows[crop];
+  const long r0 = row_off[crop];
+  float w[128];
+  {
+    const float4* wp = (const float4*)(whh + ((long)dir * 512 + j) * 128);
+#pragma unroll
+    for (int k = 0; k < 32; k++) { const float4 v = wp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+  }
+  if (j < 128) hs[j] = 0.f;
+  float c = 0.f;
+  __syncthreads();
+  int t = dir == 0 ? 0 : n - 1;
+  float gnext = n > 0 ? gx[(r0 + t) * 1024 + dir * 512 + j] : 0.f;
+  for (int step = 0; step < n; step++) {
+    const float g0 = gnext;
+    const int tn = dir == 0 ? t + 1 : t - 1;
+    if (step + 1 < n) gnext = gx[(r0 + tn) * 1024 + dir * 512 + j];   // prefetch, independent of h
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      const float4 h4 = ((const float4*)hs)[k];
+      a0 = fmaf(w[4 * k], h4.x, a0); a1 = fmaf(w[4 * k + 1], h4.y, a1);
+      a2 = fmaf(w[4 * k + 2], h4.z, a2); a3 = fmaf(w[4 * k + 3], h4.w, a3);
+    }
+    gate[j] = g0 + (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (j < 128) {
+      const float ig = 1.f / (1.f + __expf(-gate[j]));
+      const float fg = 1.f / (1.f + __expf(-gate[128 + j]));
+      const float gg = tanhf(gate[256 + j]);
+      const float og = 1.f / (1.f + __expf(-gate[384 + j]));
+      c = fg * c + ig * gg;
+      const float h = og * tanhf(c);
+      hs[j] = h;
+      hout[(r0 + t) * 256 + dir * 128 + j] = f32_to_bf16(h);
+    }
+    __syncthreads();
+    t = tn;
+  }
+}
+
+// per-frame activation of the classifier scores: log-softmax (powerset) or sigmoid (multi-label)
+__global__ void seg_activation_kernel(const float* __restrict__ logits, int ld, float* __restrict__ out, int C, int rows, int powerset) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = logits + (long)r * ld;
+  if (powerset) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; c++) mx = fmaxf(mx, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; c++) s += expf(p[c] - mx);
+    const float lse = mx + logf(s);
+    for (int c = 0; c < C; c++) out[(long)r * C + c] = p[c] - lse;
+  } else {
+    for (int c = 0; c < C; c++) out[(long)r * C + c] = 1.f / (1.f + expf(-p[c]));
+  }
+}
+
+struct HostT { std::vector<float> data; };
+
+inline bf16_t h2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+struct SincNetW {
+  float *nw, *nb, *filt_t, *filt_sum, *n0g, *n0b, *n1g, *n1b, *n2g, *n2b, *b1, *b2;
+  bf16_t *W1, *W2;  // conv k5: [60][448] (5 x 80 padded) and [60][320] (5 x 64)
+};
+
+}  // namespace
+
+struct ccx_speaker {
+  ccx_ctx* ctx = nullptr;
+  int kind = 0;            // 0 = x-vector embedder, 1 = PyanNet segmentation
+  int n_classes = 0, powerset = 1;
+  int max_crops = 0;
+  long max_samples = 0;
+  bool finalized = false;
+  std::map<std::string, HostT> staged;
+  std::vector<void*> allocs;
+  SincNetW sn{};
+  // x-vector
+  bf16_t* Wt[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // TDNN weights, tap-major [taps][N][Kpad]
+  float *bt[5] = {}, *sct[5] = {}, *sht[5] = {};
+  bf16_t* Wemb = nullptr; float* bemb = nullptr;
+  // pyannet
+  bf16_t* Wih[4] = {}; float* bih[4] = {}; float* whh[4] = {};
+  bf16_t *Wl0 = nullptr, *Wl1 = nullptr, *Wcls = nullptr; float *bl0 = nullptr, *bl1 = nullptr, *bcls = nullptr;
+  // workspaces
+  long R1cap = 0;
+  float2* ac = nullptr;
+  float *s1 = nullptr, *c2 = nullptr, *c3 = nullptr, *acc = nullptr, *gx = nullptr, *logit = nullptr;
+  bf16_t *s1n = nullptr, *s2n = nullptr, *s3n = nullptr, *a1 = nullptr, *a2 = nullptr, *a5 = nullptr, *pooled = nullptr, *hA = nullptr, *hB = nullptr;
+  long* crop_off = nullptr;
+  int *crop_len = nullptr, *off1 = nullptr, *off2 = nullptr, *off3 = nullptr, *nF1 = nullptr, *nF2 = nullptr, *nF3 = nullptr, *nFv = nullptr;
+};
+
+namespace {
+
+#define PTRY(expr)        \
+  do {                    \
+    int _rc = (expr);     \
+    if (_rc) return _rc;  \
+  } while (0)
+
+template <typename T>
+int palloc(ccx_speaker* s, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = ccx_align(count * sizeof(T), 256);
+  CCX_HIP(s->ctx, hipMalloc(&p, bytes));
+  CCX_HIP(s->ctx, hipMemset(p, 0, bytes));
+  s->allocs.push_back(p);
+  *out = (T*)p;
+  return CCX_OK;
+}
+int pup_f32(ccx_speaker* s, float** out, const float* src, size_t n) {
+  PTRY(palloc(s, out, n));
+  CCX_HIP(s->ctx, hipMemcpy(*out, src, n * 4, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+int pup_bf16(ccx_speaker* s, bf16_t** out, const std::vector<float>& src) {
+  std::vector<bf16_t> tmp(src.size());
+  for (size_t i = 0; i < src.size(); i++) tmp[i] = h2bf(src[i]);
+  PTRY(palloc(s, out, src.size()));
+  CCX_HIP(s->ctx, hipMemcpy(*out, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  return CCX_OK;
+}
+int pneed(ccx_speaker* s, const std::string& name, size_t numel, const HostT** out) {
+  auto it = s->staged.find(name);
+  if (it == s->staged.end()) return ccx_fail(s->ctx, CCX_ERR_MISSING, "speaker: tensor '%s' was never set", name.c_str());
+  if (it->second.data.size() != numel)
+    return ccx_fail(s->ctx, CCX_ERR_ARG, "speaker: tensor '%s' has %zu elements, expected %zu", name.c_str(), it->second.data.size(), numel);
+  *out = &it->second;
+  return CCX_OK;
+}
+#define PNEED(var, name, numel) \
+  const HostT* var = nullptr;   \
+  PTRY(pneed(s, (name), (size_t)(numel), &var));
+
+// Conv1d weight [O][I][k] -> GEMM weight [O][Kpad], column tap*Ipad + c
+std::vector<float> conv_w(const std::vector<float>& w, int O, int I, int k, int Ipad, int Kpad) {
+  std::vector<float> r((size_t)O * Kpad, 0.f);
+  for (int o = 0; o < O; o++)
+    for (int c = 0; c < I; c++)
+      for (int t = 0; t < k; t++) r[(size_t)o * Kpad + t * Ipad + c] = w[((size_t)o * I + c) * k + t];
+  return r;
+}
+// one tap of a Conv1d weight [O][I][k] -> [O][Ipad]
+std::vector<float> conv_tap(const std::vector<float>& w, int O, int I, int k, int tap, int Ipad) {
+  std::vector<float> r((size_t)O * Ipad, 0.f);
+  for (int o = 0; o < O; o++)
+    for (int c = 0; c < I; c++) r[(size_t)o * Ipad + c] = w[((size_t)o * I + c) * k + tap];
+  return r;
+}
+
+int load_sincnet(ccx_speaker* s, const std::string& pre) {
+  SincNetW& n = s->sn;
+  PNEED(nw, pre + "wav_norm1d.weight", 1); PNEED(nb, pre + "wav_norm1d.bias", 1);
+  PNEED(fl, pre + "conv1d.0.filters", SN_F * SN_K);
+  PNEED(w1, pre + "conv1d.1.weight", 60 * 80 * 5); PNEED(b1, pre + "conv1d.1.bias", 60);
+  PNEED(w2, pre + "conv1d.2.weight", 60 * 60 * 5); PNEED(b2, pre + "conv1d.2.bias", 60);
+  PNEED(g0, pre + "norm1d.0.weight", 80); PNEED(be0, pre + "norm1d.0.bias", 80);
+  PNEED(g1, pre + "norm1d.1.weight", 60); PNEED(be1, pre + "norm1d.1.bias", 60);
+  PNEED(g2, pre + "norm1d.2.weight", 60); PNEED(be2, pre + "norm1d.2.bias", 60);
+  std::vector<float> ft((size_t)SN_K * SN_F), fs(SN_F, 0.f);
+  for (int f = 0; f < SN_F; f++)
+    for (int k = 0; k < SN_K; k++) { ft[(size_t)k * SN_F + f] = fl->data[(size_t)f * SN_K + k]; fs[f] += fl->data[(size_t)f * SN_K + k]; }
+  PTRY(pup_f32(s, &n.nw, nw->data.data(), 1)); PTRY(pup_f32(s, &n.nb, nb->data.data(), 1));
+  PTRY(pup_f32(s, &n.filt_t, ft.data(), ft.size())); PTRY(pup_f32(s, &n.filt_sum, fs.data(), fs.size()));
+  PTRY(pup_bf16(s, &n.W1, conv_w(w1->data, 60, 80, 5, 80, 448))); PTRY(pup_f32(s, &n.b1, b1->data.data(), 60));
+  PTRY(pup_bf16(s, &n.W2, conv_w(w2->data, 60, 60, 5, 64, 320))); PTRY(pup_f32(s, &n.b2, b2->data.data(), 60));
+  PTRY(pup_f32(s, &n.n0g, g0->data.data(), 80)); PTRY(pup_f32(s, &n.n0b, be0->data.data(), 80));
+  PTRY(pup_f32(s, &n.n1g, g1->data.data(), 60)); PTRY(pup_f32(s, &n.n1b, be1->data.data(), 60));
+  PTRY(pup_f32(s, &n.n2g, g2->data.data(), 60)); PTRY(pup_f32(s, &n.n2b, be2->data.data(), 60));
+  return CCX_OK;
+}
+
+struct Plan {
+  int n = 0;
+  long R1 = 0, R2 = 0, R3 = 0;
+  std::vector<long> coff;
+  std::vector<int> clen, off1, off2, off3, f1, f2, f3, fv;
+};
+
+int make_plan(ccx_speaker* s, const int* n_samples, const int64_t* offsets, int n, Plan& P) {
+  ccx_ctx* ctx = s->ctx;
+  P.n = n;
+  P.coff.resize(n); P.clen.resize(n); P.off1.resize(n); P.off2.resize(n); P.off3.resize(n);
+  P.f1.resize(n); P.f2.resize(n); P.f3.resize(n); P.fv.resize(n);
+  for (int i = 0; i < n; i++) {
+    const int T = n_samples[i];
+    const int f1c = (T - SN_K) / SN_STRIDE + 1, f1 = T >= SN_K ? f1c / 3 : 0;
+    const int f2 = (f1 - 4) / 3, f3 = (f2 - 4) / 3;
+    CCX_REQUIRE(ctx, T >= SN_K && f1 >= 5 && f2 >= 5 && f3 >= 1, "speaker: crop %d (%d samples) is too short for the SincNet front end", i, T);
+    const int fv = f3 - 14;  // after the TDNN's valid convolutions (k5 d1, k3 d2, k3 d3)
+    CCX_REQUIRE(ctx, s->kind != 0 || fv >= 2, "speaker: crop %d (%d samples) is too short for the x-vector TDNN", i, T);
+    P.coff[i] = offsets[i]; P.clen[i] = T; P.f1[i] = f1; P.f2[i] = f2; P.f3[i] = f3; P.fv[i] = fv;
+    P.off1[i] = (int)P.R1; P.off2[i] = (int)P.R2; P.off3[i] = (int)P.R3;
+    P.R1 += f1; P.R2 += f2; P.R3 += f3;
+  }
+  CCX_REQUIRE(ctx, P.R1 <= s->R1cap, "speaker: %ld front-end frames exceed capacity %ld", P.R1, s->R1cap);
+  return CCX_OK;
+}
+
+int upload_plan(ccx_speaker* s, const Plan& P, hipStream_t st) {
+  ccx_ctx* ctx = s->ctx;
+#define UPI(dst, vec) CCX_HIP(ctx, hipMemcpyAsync(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, st))
+  UPI(s->crop_off, P.coff); UPI(s->crop_len, P.clen); UPI(s->off1, P.off1); UPI(s->off2, P.off2); UPI(s->off3, P.off3);
+  UPI(s->nF1, P.f1); UPI(s->nF2, P.f2); UPI(s->nF3, P.f3); UPI(s->nFv, P.fv);
+#undef UPI
+  CCX_HIP(ctx, hipStreamSynchronize(st));
+  return CCX_OK;
+}
+
+// SincNet over all crops: leaves s3n [R3][64] bf16 (60 channels + zero pad)
+int run_sincnet(ccx_speaker* s, const float* wav, const Plan& P, hipStream_t st) {
+  ccx_ctx* ctx = s->ctx;
+  const SincNetW& n = s->sn;
+  hipLaunchKernelGGL(wav_stats_kernel, dim3(P.n), dim3(256), 0, st, wav, s->crop_off, s->crop_len, n.nw, n.nb, s->ac);
+  CCX_CHECK_LAUNCH(ctx);
+  int maxp = 0;
+  for (int i = 0; i < P.n; i++) maxp = P.f1[i] > maxp ? P.f1[i] : maxp;
+  {
+    ccx_prof_scope ps(ctx, st, "sinc_conv_pool_kernel", 0.0, 0.0);
+    hipLaunchKernelGGL(sinc_conv_pool_kernel, dim3(ccx_cdiv(maxp, 32), P.n), dim3(320), 0, st, wav, s->crop_off, s->crop_len, s->off1,
+                       s->nF1, s->ac, n.filt_t, n.filt_sum, s->s1);
+  }
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<1>, dim3(P.n, 2), dim3(256), 0, st, s->s1, 80, s->off1, s->s1n, 80, s->off1, s->nF1,
+                     n.n0g, n.n0b, 80);
+  CCX_CHECK_LAUNCH(ctx);
+  GemmParams p;
+  memset(&p, 0, sizeof(p));   // conv1d(80 -> 60, k5) as a GEMM over a strided view: row m = frames m..m+4
+  p.A = s->s1n; p.lda = 80; p.W = n.W1; p.ldw = 448; p.M = (int)P.R1; p.N = 60; p.K = 448; p.bias = n.b1; p.out = s->c2; p.ldo = 128;
+  PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<3>, dim3(P.n, 1), dim3(256), 0, st, s->c2, 128, s->off1, s->s2n, 64, s->off2, s->nF2,
+                     n.n1g, n.n1b, 60);
+  CCX_CHECK_LAUNCH(ctx);
+  memset(&p, 0, sizeof(p));   // conv1d(60 -> 60, k5), channels padded to 64
+  p.A = s->s2n; p.lda = 64; p.W = n.W2; p.ldw = 320; p.M = (int)P.R2; p.N = 60; p.K = 320; p.bias = n.b2; p.out = s->c3; p.ldo = 128;
+  PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<3>, dim3(P.n, 1), dim3(256), 0, st, s->c3, 128, s->off2, s->s3n, 64, s->off3, s->nF3,
+                     n.n2g, n.n2b, 60);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccx_speaker_create(ccx_ctx* ctx, int kind, int n_classes, int powerset, int max_crops, int64_t max_samples, ccx_speaker** out) {
+  if (!ctx) return CCX_ERR_ARG;
+  CCX_REQUIRE(ctx, out && (kind == 0 || kind == 1), "ccx_speaker_create: kind must be 0 (x-vector) or 1 (PyanNet)");
+  CCX_REQUIRE(ctx, kind == 0 || (n_classes >= 1 && n_classes <= 64), "ccx_speaker_create: n_classes out of range");
+  CCX_REQUIRE(ctx, max_crops >= 1 && max_samples >= 1024, "ccx_speaker_create: capacity too small");
+  ccx_speaker* s = new ccx_speaker();
+  s->ctx = ctx; s->kind = kind; s->n_classes = n_classes; s->powerset = powerset; s->max_crops = max_crops; s->max_samples = max_samples;
+  *out = s;
+  return CCX_OK;
+}
+
+void ccx_speaker_destroy(ccx_speaker* s) {
+  if (!s) return;
+  for (void* p : s->allocs) hipFree(p);
+  delete s;
+}
+
+int ccx_speaker_set_tensor(ccx_speaker* s, const char* name, const float* data, int64_t numel) {
+  if (!s) return CCX_ERR_ARG;
+  CCX_REQUIRE(s->ctx, !s->finalized && name && data && numel > 0, "speaker: set_tensor bad arguments");
+  HostT t;
+  t.data.resize((size_t)numel);
+  CCX_HIP(s->ctx, hipMemcpy(t.data.data(), data, (size_t)numel * 4, hipMemcpyDefault));
+  s->staged[std::string(name)] = std::move(t);
+  return CCX_OK;
+}
+
+int ccx_speaker_finalize(ccx_speaker* s) {
+  if (!s) return CCX_ERR_ARG;
+  CCX_REQUIRE(s->ctx, !s->finalized, "speaker: finalize called twice");
+  PTRY(load_sincnet(s, "sincnet."));
+  if (s->kind == 0) {
+    const int outc[5] = {512, 512, 512, 512, 1500}, ks[5] = {5, 3, 3, 1, 1}, inc[5] = {60, 512, 512, 512, 512};
+    for (int l = 0; l < 5; l++) {
+      const std::string p = "tdnns." + std::to_string(l);
+      PNEED(w, p + ".0.weight", (size_t)outc[l] * inc[l] * ks[l]); PNEED(b, p + ".0.bias", outc[l]);
+      PNEED(g, p + ".2.weight", outc[l]); PNEED(be, p + ".2.bias", outc[l]);
+      PNEED(rm, p + ".2.running_mean", outc[l]); PNEED(rv, p + ".2.running_var", outc[l]);
+      std::vector<float> sc(outc[l]), sh(outc[l]);
+      for (int c = 0; c < outc[l]; c++) { sc[c] = g->data[c] / sqrtf(rv->data[c] + 1e-5f); sh[c] = be->data[c] - rm->data[c] * sc[c]; }
+      PTRY(pup_f32(s, &s->bt[l], b->data.data(), outc[l])); PTRY(pup_f32(s, &s->sct[l], sc.data(), outc[l])); PTRY(pup_f32(s, &s->sht[l], sh.data(), outc[l]));
+      std::vector<float> all;
+      if (l == 0) all = conv_w(w->data, 512, 60, 5, 64, 320);   // dilation 1: one GEMM over the 5-frame view
+      else
+        for (int t = 0; t < ks[l]; t++) { auto tap = conv_tap(w->data, outc[l], inc[l], ks[l], t, 512); all.insert(all.end(), tap.begin(), tap.end()); }
+      PTRY(pup_bf16(s, &s->Wt[l], all));
+    }
+    PNEED(we, "embedding.weight", 512 * 3000); PNEED(bemb, "embedding.bias", 512);
+    std::vector<float> wp((size_t)512 * 3072, 0.f);
+    for (int o = 0; o < 512; o++) for (int k = 0; k < 3000; k++) wp[(size_t)o * 3072 + k] = we->data[(size_t)o * 3000 + k];
+    PTRY(pup_bf16(s, &s->Wemb, wp)); PTRY(pup_f32(s, &s->bemb, bemb->data.data(), 512));
+  } else {
+    for (int l = 0; l < 4; l++) {
+      const int in = l == 0 ? 60 : 256, inp = l == 0 ? 64 : 256;
+      std::vector<float> wih((size_t)1024 * inp, 0.f), bias(1024), whh((size_t)2 * 512 * 128);
+      for (int dir = 0; dir < 2; dir++) {
+        const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
+        PNEED(wi, "lstm.weight_ih" + sfx, (size_t)512 * in); PNEED(wh, "lstm.weight_hh" + sfx, 512 * 128);
+        PNEED(bi, "lstm.bias_ih" + sfx, 512); PNEED(bh, "lstm.bias_hh" + sfx, 512);
+        for (int r = 0; r < 512; r++) {
+          for (int k = 0; k < in; k++) wih[(size_t)(dir * 512 + r) * inp + k] = wi->data[(size_t)r * in + k];
+          bias[dir * 512 + r] = bi->data[r] + bh->data[r];
+          for (int k = 0; k < 128; k++) whh[((size_t)dir * 512 + r) * 128 + k] = wh->data[(size_t)r * 128 + k];
+        }
+      }
+      PTRY(pup_bf16(s, &s->Wih[l], wih)); PTRY(pup_f32(s, &s->bih[l], bias.data(), 1024)); PTRY(pup_f32(s, &s->whh[l], whh.data(), whh.size()));
+    }
+    PNEED(l0w, "linear.0.weight", 128 * 256); PNEED(l0b, "linear.0.bias", 128);
+    PNEED(l1w, "linear.1.weight", 128 * 128); PNEED(l1b, "linear.1.bias", 128);
+    PNEED(cw, "classifier.weight", (size_t)s->n_classes * 128); PNEED(cb, "classifier.bias", s->n_classes);
+    PTRY(pup_bf16(s, &s->Wl0, l0w->data)); PTRY(pup_f32(s, &s->bl0, l0b->data.data(), 128));
+    PTRY(pup_bf16(s, &s->Wl1, l1w->data)); PTRY(pup_f32(s, &s->bl1, l1b->data.data(), 128));
+    PTRY(pup_bf16(s, &s->Wcls, cw->data)); PTRY(pup_f32(s, &s->bcls, cb->data.data(), s->n_classes));
+  }
+  s->staged.clear();
+  // capacity: pooled sinc frames <= samples / 30
+  s->R1cap = s->max_samples / 30 + 8 * (long)s->max_crops;
+  const size_t R1 = (size_t)s->R1cap + 16, R2 = R1 / 3 + 16, R3 = R2 / 3 + 16, C = (size_t)s->max_crops;
+  PTRY(palloc(s, &s->ac, C)); PTRY(palloc(s, &s->s1, R1 * 80)); PTRY(palloc(s, &s->s1n, R1 * 80 + 1024));
+  PTRY(palloc(s, &s->c2, R1 * 128)); PTRY(palloc(s, &s->s2n, R2 * 64 + 1024)); PTRY(palloc(s, &s->c3, R2 * 128)); PTRY(palloc(s, &s->s3n, R3 * 64 + 1024));
+  PTRY(palloc(s, &s->crop_off, C)); PTRY(palloc(s, &s->crop_len, C));
+  PTRY(palloc(s, &s->off1, C)); PTRY(palloc(s, &s->off2, C)); PTRY(palloc(s, &s->off3, C));
+  PTRY(palloc(s, &s->nF1, C)); PTRY(palloc(s, &s->nF2, C)); PTRY(palloc(s, &s->nF3, C)); PTRY(palloc(s, &s->nFv, C));
+  if (s->kind == 0) {
+    PTRY(palloc(s, &s->a1, (R3 + 16) * 512)); PTRY(palloc(s, &s->a2, (R3 + 16) * 512)); PTRY(palloc(s, &s->acc, (R3 + 16) * 512));
+    PTRY(palloc(s, &s->a5, (R3 + 16) * 1536)); PTRY(palloc(s, &s->pooled, C * 3072 + 1024));
+  } else {
+    PTRY(palloc(s, &s->gx, R3 * 1024)); PTRY(palloc(s, &s->hA, R3 * 256 + 1024)); PTRY(palloc(s, &s->hB, R3 * 256 + 1024));
+    PTRY(palloc(s, &s->logit, R3 * 128));
+  }
+  s->finalized = true;
+  return CCX_OK;
+}
+
+// x-vector: wav_dev holds the crops at `offsets[i]` (in samples) with n_samples[i] each -> out_dev [n][512] f32
+int ccx_speaker_embed(ccx_speaker* s, const float* wav, const int64_t* offsets, const int* n_samples, int n, float* out, void* stream_) {
+  if (!s) return CCX_ERR_ARG;
+  ccx_ctx* ctx = s->ctx;
+  hipStream_t st = (hipStream_t)stream_;
+  CCX_REQUIRE(ctx, s->finalized && s->kind == 0 && wav && offsets && n_samples && out && n >= 1 && n <= s->max_crops, "speaker_embed: bad arguments (n=%d, max %d)", n, s->max_crops);
+  Plan P;
+  PTRY(make_plan(s, n_samples, offsets, n, P));
+  PTRY(upload_plan(s, P, st));
+  PTRY(run_sincnet(s, wav, P, st));
+  const int R3 = (int)P.R3;
+  GemmParams p;
+  // tdnn 0: k5 d1 over the 5-frame view of s3n
+  memset(&p, 0, sizeof(p));
+  p.A = s->s3n; p.lda = 64; p.W = s->Wt[0]; p.ldw = 320; p.M = R3; p.N = 512; p.K = 320; p.bias = s->bt[0]; p.out = s->a1; p.ldo = 512;
+  p.scale = s->sct[0]; p.shift = s->sht[0]; p.slope = 0.01f;
+  PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+  // tdnn 1 (d2) and 2 (d3): three accumulated taps each
+  bf16_t* src = s->a1; bf16_t* dst = s->a2;
+  for (int l = 1; l <= 2; l++) {
+    const int dil = l + 1;
+    for (int tap = 0; tap < 3; tap++) {
+      memset(&p, 0, sizeof(p));
+      p.A = src + (long)tap * dil * 512; p.lda = 512; p.W = s->Wt[l] + (long)tap * 512 * 512; p.ldw = 512; p.M = R3; p.N = 512; p.K = 512;
+      if (tap == 0) { p.bias = s->bt[l]; p.out = s->acc; p.ldo = 512; PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st)); }
+      else if (tap == 1) { p.out = s->acc; p.ldo = 512; p.resid = s->acc; p.ldr = 512; PTRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st)); }
+      else {
+        p.out = dst; p.ldo = 512; p.resid = s->acc; p.ldr = 512; p.scale = s->sct[l]; p.shift = s->sht[l]; p.slope = 0.01f;
+        PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+      }
+    }
+    bf16_t* t = src; src = dst; dst = t;
+  }
+  // tdnn 3 (k1) and 4 (k1, 1500 channels)
+  memset(&p, 0, sizeof(p));
+  p.A = src; p.lda = 512; p.W = s->Wt[3]; p.ldw = 512; p.M = R3; p.N = 512; p.K = 512; p.bias = s->bt[3]; p.out = dst; p.ldo = 512;
+  p.scale = s->sct[3]; p.shift = s->sht[3]; p.slope = 0.01f;
+  PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+  memset(&p, 0, sizeof(p));
+  p.A = dst; p.lda = 512; p.W = s->Wt[4]; p.ldw = 512; p.M = R3; p.N = 1500; p.K = 512; p.bias = s->bt[4]; p.out = s->a5; p.ldo = 1536;
+  p.scale = s->sct[4]; p.shift = s->sht[4]; p.slope = 0.01f;
+  PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+  hipLaunchKernelGGL(stats_pool_kernel, dim3(n, ccx_cdiv(1500, 256)), dim3(256), 0, st, s->a5, 1536, s->off3, s->nFv, s->pooled, 3072, 1500);
+  CCX_CHECK_LAUNCH(ctx);
+  // embedding Linear(3000 -> 512); out rows are 512 wide
+  memset(&p, 0, sizeof(p));
+  p.A = s->pooled; p.lda = 3072; p.W = s->Wemb; p.ldw = 3072; p.M = n; p.N = 512; p.K = 3072; p.bias = s->bemb; p.out = out; p.ldo = 512;
+  PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+  return CCX_OK;
+}
+
+// PyanNet: scores for every SincNet frame of every crop.  frames_out[i] (host) receives the frame count of
+// crop i; out_dev is [sum frames][n_classes] f32 in crop order.
+int ccx_speaker_segment(ccx_speaker* s, const float* wav, const int64_t* offsets, const int* n_samples, int n, float* out,
+                        int64_t out_capacity_rows, int* frames_out, void* stream_) {
+  if (!s) return CCX_ERR_ARG;
+  ccx_ctx* ctx = s->ctx;
+  hipStream_t st = (hipStream_t)stream_;
+  CCX_REQUIRE(ctx, s->finalized && s->kind == 1 && wav && offsets && n_samples && out && frames_out && n >= 1 && n <= s->max_crops, "speaker_segment: bad arguments");
+  Plan P;
+  PTRY(make_plan(s, n_samples, offsets, n, P));
+  CCX_REQUIRE(ctx, P.R3 <= out_capacity_rows, "speaker_segment: output needs %ld rows, capacity %ld", P.R3, (long)out_capacity_rows);
+  for (int i = 0; i < n; i++) frames_out[i] = P.f3[i];
+  PTRY(upload_plan(s, P, st));
+  PTRY(run_sincnet(s, wav, P, st));
+  const int R3 = (int)P.R3;
+  GemmParams p;
+  const bf16_t* x = s->s3n;
+  long ldx = 64; int K = 64;
+  bf16_t* hbuf[2] = {s->hA, s->hB};
+  for (int l = 0; l < 4; l++) {
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.lda = ldx; p.W = s->Wih[l]; p.ldw = K; p.M = R3; p.N = 1024; p.K = K; p.bias = s->bih[l]; p.out = s->gx; p.ldo = 1024;
+    PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+    {
+      ccx_prof_scope ps(ctx, st, "lstm_recurrent_kernel", 0.0, 0.0);
+      hipLaunchKernelGGL(lstm_recurrent_kernel, dim3(n, 2), dim3(512), 0, st, s->gx, s->whh[l], s->off3, s->nF3, hbuf[l & 1]);
+    }
+    CCX_CHECK_LAUNCH(ctx);
+    x = hbuf[l & 1]; ldx = 256; K = 256;
+  }
+  bf16_t* t0 = hbuf[0];  // layer 3 wrote hbuf[1]; reuse hbuf[0] for the linear outputs ([R3][128] fits in [R3][256])
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.lda = 256; p.W = s->Wl0; p.ldw = 256; p.M = R3; p.N = 128; p.K = 256; p.bias = s->bl0; p.out = t0; p.ldo = 128; p.slope = 0.01f;
+  PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+  bf16_t* t1 = hbuf[1];
+  memset(&p, 0, sizeof(p));
+  p.A = t0; p.lda = 128; p.W = s->Wl1; p.ldw = 128; p.M = R3; p.N = 128; p.K = 128; p.bias = s->bl1; p.out = t1; p.ldo = 128; p.slope = 0.01f;
+  PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
+  memset(&p, 0, sizeof(p));
+  p.A = t1; p.lda = 128; p.W = s->Wcls; p.ldw = 128; p.M = R3; p.N = s->n_classes; p.K = 128; p.bias = s->bcls; p.out = s->logit; p.ldo = 128;
+  PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
+  hipLaunchKernelGGL(seg_activation_kernel, dim3(ccx_cdiv(R3, 256)), dim3(256), 0, st, s->logit, 128, out, s->n_classes, R3, s->powerset);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+}  // extern "C"

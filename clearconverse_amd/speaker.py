@@ -1,0 +1,116 @@
+"""libccx-backed speaker networks.
+
+`XVectorEmbedder` is the drop-in for `self.embedding_model` of the reference
+(Inference("pyannote/embedding", window="whole"), /root/reference/back/api.py:776-780): calling it
+with {"waveform": Tensor[1,T], "sample_rate": 16000} returns a 1-D numpy embedding, exactly the call at
+back/api.py:869-872.  `embed_batch` is the batched entry the reference lacks (ragged crops, one launch
+chain).  `SegmentationNet` is the PyanNet the VAD / diarization pipelines run (see pipelines.py)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import sinc_filters
+
+
+class _SpeakerNet:
+    def __init__(self, kind: int, state_dict: Dict[str, torch.Tensor], n_classes: int, powerset: bool, max_crops: int,
+                 max_samples: int, device: int, ctx: Optional[_lib.Context]):
+        if not torch.cuda.is_available():
+            raise _lib.CcxError("speaker networks need a ROCm GPU: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.ctx = ctx or _lib.Context(device)
+        self.lib = self.ctx.lib
+        self.max_crops, self.max_samples = int(max_crops), int(max_samples)
+        h = C.c_void_p()
+        self.ctx.check(self.lib.ccx_speaker_create(self.ctx.handle, kind, n_classes, 1 if powerset else 0, self.max_crops,
+                                                   self.max_samples, C.byref(h)), "ccx_speaker_create")
+        self.handle = h
+        sd = dict(state_dict)
+        lo, band = sd.pop("sincnet.conv1d.0.filterbank.low_hz_"), sd.pop("sincnet.conv1d.0.filterbank.band_hz_")
+        sd["sincnet.conv1d.0.filters"] = sinc_filters(lo, band)
+        for name, t in sd.items():
+            if not torch.is_tensor(t) or name in ("powerset",):
+                continue
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            self.ctx.check(self.lib.ccx_speaker_set_tensor(self.handle, name.encode(), t.data_ptr(), t.numel()), f"set_tensor({name})")
+        self.ctx.check(self.lib.ccx_speaker_finalize(self.handle), "ccx_speaker_finalize")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ccx_speaker_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pack(self, crops: Sequence):
+        """Concatenate crops (1-D tensors/arrays, any device) into one device buffer + offset table."""
+        ts = []
+        for c in crops:
+            t = c if torch.is_tensor(c) else torch.from_numpy(np.asarray(c, dtype=np.float32))
+            ts.append(t.reshape(-1).to(self.device, torch.float32))
+        lens = [int(t.numel()) for t in ts]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        buf = torch.cat(ts) if len(ts) > 1 else ts[0].contiguous()
+        return buf, offs, np.asarray(lens, dtype=np.int32)
+
+
+class XVectorEmbedder(_SpeakerNet):
+    DIM = 512
+
+    def __init__(self, state_dict, max_crops: int = 256, max_samples: int = 16000 * 600, device: int = 0, ctx=None):
+        super().__init__(0, state_dict, 0, True, max_crops, max_samples, device, ctx)
+
+    def embed_batch(self, crops: Sequence) -> torch.Tensor:
+        """crops: list of 1-D waveforms (16 kHz) -> [n, 512] f32 tensor on the GPU."""
+        out = torch.empty(len(crops), self.DIM, device=self.device, dtype=torch.float32)
+        for i0 in range(0, len(crops), self.max_crops):
+            part = crops[i0:i0 + self.max_crops]
+            buf, offs, lens = self._pack(part)
+            o = out[i0:i0 + len(part)]
+            self.ctx.check(self.lib.ccx_speaker_embed(self.handle, buf.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                      lens.ctypes.data_as(C.POINTER(C.c_int)), len(part), o.data_ptr(),
+                                                      _lib.current_stream_ptr()), "ccx_speaker_embed")
+        return out
+
+    def __call__(self, item: dict) -> np.ndarray:
+        """pyannote Inference(window='whole') call shape: {'waveform': [1,T], 'sample_rate': sr} -> np [512]."""
+        if int(item.get("sample_rate", 16000)) != 16000:
+            raise _lib.CcxError("XVectorEmbedder expects 16 kHz input (the reference always passes target_sample_rate)")
+        w = item["waveform"]
+        return self.embed_batch([w.reshape(-1)])[0].cpu().numpy()
+
+
+class SegmentationNet(_SpeakerNet):
+    """PyanNet: frames of per-class scores for each crop (SincNet frame rate: 1 frame per 270 samples)."""
+
+    def __init__(self, state_dict, n_classes: int = 7, powerset: bool = True, max_crops: int = 256,
+                 max_samples: int = 16000 * 600, device: int = 0, ctx=None):
+        super().__init__(1, state_dict, n_classes, powerset, max_crops, max_samples, device, ctx)
+        self.n_classes = n_classes
+
+    def segment_batch(self, crops: Sequence) -> List[torch.Tensor]:
+        outs: List[torch.Tensor] = []
+        for i0 in range(0, len(crops), self.max_crops):
+            part = crops[i0:i0 + self.max_crops]
+            buf, offs, lens = self._pack(part)
+            cap = int(sum(lens) // 270 + 4 * len(part))
+            out = torch.empty(cap, self.n_classes, device=self.device, dtype=torch.float32)
+            frames = np.zeros(len(part), dtype=np.int32)
+            self.ctx.check(self.lib.ccx_speaker_segment(self.handle, buf.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                        lens.ctypes.data_as(C.POINTER(C.c_int)), len(part), out.data_ptr(), cap,
+                                                        frames.ctypes.data_as(C.POINTER(C.c_int)), _lib.current_stream_ptr()),
+                           "ccx_speaker_segment")
+            r = 0
+            for f in frames:
+                outs.append(out[r:r + int(f)])
+                r += int(f)
+        return outs

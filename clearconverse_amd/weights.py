@@ -175,3 +175,85 @@ def synthetic_sepformer_state_dict(dims: SepDims, seed: int = 0) -> Dict[str, to
     sd["masknet.model.output_fc.1.weight"] = torch.randn(dims.n_filters * dims.n_spk, D, 1, generator=g) / math.sqrt(D)
     sd["masknet.model.output_fc.1.bias"] = 0.1 * torch.randn(dims.n_filters * dims.n_spk, generator=g)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# pyannote-style speaker networks [UPSTREAM-RECALL]: SincNet front end, XVectorSincNet, PyanNet
+# ----------------------------------------------------------------------------------------------
+def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, sample_rate: int = 16000, min_low_hz: float = 50.0,
+                 min_band_hz: float = 50.0, kernel: int = 251) -> torch.Tensor:
+    """Expand the learnable (low_hz_, band_hz_) of asteroid's ParamSincFB into its 40 cos + 40 sin
+    band-pass filters [80, kernel] (Hamming-windowed sinc differences); done once at load time."""
+    low_hz_ = low_hz_.double().view(-1, 1)
+    band_hz_ = band_hz_.double().view(-1, 1)
+    half = kernel // 2
+    n_lin = torch.linspace(0, kernel / 2 - 1, steps=half, dtype=torch.float64)
+    window = 0.54 - 0.46 * torch.cos(2 * math.pi * n_lin / kernel)
+    n_ = 2 * math.pi * torch.arange(-half, 0, dtype=torch.float64).view(1, -1) / sample_rate
+    low = min_low_hz + low_hz_.abs()
+    high = torch.clamp(low + min_band_hz + band_hz_.abs(), min_low_hz, sample_rate / 2)
+    band = (high - low)[:, 0]
+    ft_low, ft_high = low @ n_, high @ n_
+    cos_l = ((torch.sin(ft_high) - torch.sin(ft_low)) / (n_ / 2)) * window
+    sin_l = ((torch.cos(ft_low) - torch.cos(ft_high)) / (n_ / 2)) * window
+    cos_f = torch.cat([cos_l, 2 * band.view(-1, 1), torch.flip(cos_l, dims=[1])], dim=1)
+    sin_f = torch.cat([sin_l, torch.zeros_like(band.view(-1, 1)), -torch.flip(sin_l, dims=[1])], dim=1)
+    return (torch.cat([cos_f, sin_f], dim=0) / (2 * band.repeat(2)[:, None])).float()
+
+
+def _synthetic_sincnet(sd: Dict[str, torch.Tensor], g: torch.Generator, prefix: str = "sincnet."):
+    import numpy as np
+    to_mel = lambda hz: 2595 * np.log10(1 + hz / 700)
+    to_hz = lambda mel: 700 * (10 ** (mel / 2595) - 1)
+    hz = to_hz(np.linspace(to_mel(30.0), to_mel(16000 / 2 - 100.0), 41))
+    sd[prefix + "conv1d.0.filterbank.low_hz_"] = torch.tensor(hz[:-1], dtype=torch.float32).view(-1, 1)
+    sd[prefix + "conv1d.0.filterbank.band_hz_"] = torch.tensor(np.diff(hz), dtype=torch.float32).view(-1, 1)
+    sd[prefix + "wav_norm1d.weight"] = torch.tensor([1.1])
+    sd[prefix + "wav_norm1d.bias"] = torch.tensor([0.05])
+    sd[prefix + "conv1d.1.weight"] = torch.randn(60, 80, 5, generator=g) / math.sqrt(400)
+    sd[prefix + "conv1d.1.bias"] = 0.1 * torch.randn(60, generator=g)
+    sd[prefix + "conv1d.2.weight"] = torch.randn(60, 60, 5, generator=g) / math.sqrt(300)
+    sd[prefix + "conv1d.2.bias"] = 0.1 * torch.randn(60, generator=g)
+    for i, c in enumerate((80, 60, 60)):
+        sd[prefix + f"norm1d.{i}.weight"] = 1 + 0.1 * torch.randn(c, generator=g)
+        sd[prefix + f"norm1d.{i}.bias"] = 0.1 * torch.randn(c, generator=g)
+
+
+def synthetic_xvector_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """`pyannote/embedding` (XVectorSincNet) key layout with seeded weights."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    _synthetic_sincnet(sd, g)
+    cin = 60
+    for i, (cout, k) in enumerate(zip((512, 512, 512, 512, 1500), (5, 3, 3, 1, 1))):
+        sd[f"tdnns.{i}.0.weight"] = torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)
+        sd[f"tdnns.{i}.0.bias"] = 0.1 * torch.randn(cout, generator=g)
+        sd[f"tdnns.{i}.2.weight"] = 1 + 0.1 * torch.randn(cout, generator=g)
+        sd[f"tdnns.{i}.2.bias"] = 0.1 * torch.randn(cout, generator=g)
+        sd[f"tdnns.{i}.2.running_mean"] = 0.1 * torch.randn(cout, generator=g)
+        sd[f"tdnns.{i}.2.running_var"] = 0.5 + torch.rand(cout, generator=g)
+        cin = cout
+    sd["embedding.weight"] = torch.randn(512, 3000, generator=g) / math.sqrt(3000)
+    sd["embedding.bias"] = 0.1 * torch.randn(512, generator=g)
+    return sd
+
+
+def synthetic_pyannet_state_dict(n_classes: int = 7, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """PyanNet (pyannote/segmentation*) key layout with seeded weights: SincNet, 4 BiLSTM(128), 2 linear, classifier."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    _synthetic_sincnet(sd, g)
+    for l in range(4):
+        cin = 60 if l == 0 else 256
+        for sfx in ("", "_reverse"):
+            sd[f"lstm.weight_ih_l{l}{sfx}"] = torch.randn(512, cin, generator=g) / math.sqrt(cin)
+            sd[f"lstm.weight_hh_l{l}{sfx}"] = torch.randn(512, 128, generator=g) / math.sqrt(128)
+            sd[f"lstm.bias_ih_l{l}{sfx}"] = 0.1 * torch.randn(512, generator=g)
+            sd[f"lstm.bias_hh_l{l}{sfx}"] = 0.1 * torch.randn(512, generator=g)
+    sd["linear.0.weight"] = torch.randn(128, 256, generator=g) / math.sqrt(256)
+    sd["linear.0.bias"] = 0.1 * torch.randn(128, generator=g)
+    sd["linear.1.weight"] = torch.randn(128, 128, generator=g) / math.sqrt(128)
+    sd["linear.1.bias"] = 0.1 * torch.randn(128, generator=g)
+    sd["classifier.weight"] = torch.randn(n_classes, 128, generator=g) / math.sqrt(128)
+    sd["classifier.bias"] = 0.1 * torch.randn(n_classes, generator=g)
+    return sd

@@ -134,6 +134,31 @@ int ccx_sepformer_finalize(ccx_sepformer* s);
 int ccx_sepformer_separate(ccx_sepformer* s, const float* mix_dev, int64_t stride, const int* n_samples, int B,
                            float* out_dev, void* stream);
 
+/* ---- pyannote-style speaker networks (replace self.embedding_model = Inference("pyannote/embedding",
+ *      window="whole"), reference back/api.py:776-780, called at back/api.py:869; and the segmentation
+ *      network inside self.vad_pipeline / self.diarization, reference back/api.py:782-792, called at
+ *      back/api.py:1311, 1056, 1124) ------------------------------------------------------------------ */
+
+typedef struct ccx_speaker ccx_speaker;
+/* kind 0: XVectorSincNet embedder (512-d).  kind 1: PyanNet segmentation (n_classes per frame; powerset
+ * != 0 -> log-softmax, else sigmoid).  max_samples: total samples of all crops of one call. */
+int ccx_speaker_create(ccx_ctx* ctx, int kind, int n_classes, int powerset, int max_crops, int64_t max_samples,
+                       ccx_speaker** out);
+void ccx_speaker_destroy(ccx_speaker* s);
+/* Tensors by pyannote checkpoint key (f32): "sincnet.wav_norm1d.weight", "sincnet.conv1d.0.filters"
+ * ([80,251] band-pass filters expanded from low_hz_/band_hz_ by the host), "sincnet.conv1d.1.weight", ...,
+ * "tdnns.N.0.weight", "tdnns.N.2.running_mean", "embedding.weight" | "lstm.weight_ih_l0_reverse",
+ * "linear.0.weight", "classifier.weight". */
+int ccx_speaker_set_tensor(ccx_speaker* s, const char* name, const float* data, int64_t numel);
+int ccx_speaker_finalize(ccx_speaker* s);
+/* n crops stored in wav_dev at sample offsets[i], n_samples[i] long (host arrays) -> out_dev [n, 512] f32 */
+int ccx_speaker_embed(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,
+                      float* out_dev, void* stream);
+/* per-frame class scores of n crops, concatenated in crop order: out_dev [sum frames, n_classes] f32;
+ * frames_out[i] (host) = frames of crop i. */
+int ccx_speaker_segment(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,
+                        float* out_dev, int64_t out_capacity_rows, int* frames_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
