@@ -75,6 +75,9 @@ PROTOTYPES = {
     "ccx_speaker_finalize": (_i, [_vp]),
     "ccx_speaker_embed": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _vp]),
     "ccx_speaker_segment": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64, _ip, _vp]),
+    "ccx_specgate_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
+    "ccx_specgate_destroy": (None, [_vp]),
+    "ccx_specgate_reduce": (_i, [_vp, _vp, _i64, _ip, _i, _f, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

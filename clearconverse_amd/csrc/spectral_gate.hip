@@ -1,0 +1,336 @@
+// spectral_gate.hip -- stationary spectral-gate denoiser (K2 in SURVEY.md section 2a).
+//
+// Replaces `nr.reduce_noise(y=..., sr=16000, stationary=True, prop_decrease=p)` (reference
+// back/api.py:349 on speaker-profile crops and 832-833 on the whole clip).  Semantics follow
+// noisereduce's SpectralGateStationary [UPSTREAM-RECALL]; CPU restatement (on scipy.signal):
+// oracle/spectral_gate_ref.py.
+//
+// Pipeline per clip (all HBM-bound, one launch per stage over all clips):
+//   STFT (n_fft 1024, hop 256, periodic Hann, zero boundary, "spectrum" scaling) of the clip itself
+//     -> per-bin dB statistics -> threshold = mean + 1.5 std          (noise profile = the signal)
+//   STFT of the clip padded with 30000 zeros each side -> dB (floored at per-bin max - 80)
+//     -> mask = dB > threshold ? 1 : 1 - p -> separable 33 x 7 triangular smoothing -> X * mask
+//     -> inverse FFT, Hann, overlap-add / window-square normalisation -> crop back to the clip.
+// The 1024-point FFTs run in LDS (radix-2, 256 threads, bit-reversed load), one block per frame.
+#include <math.h>
+#include "../../include/ccx.h"
+#include "ccx_common.h"
+
+namespace {
+
+#define SG_N 1024
+#define SG_HOP 256
+#define SG_BINS 513
+#define SG_LD 520       // row stride (bins) of the [frame][bin] matrices
+#define SG_PAD 30000
+
+__device__ __forceinline__ void fft1024(float2* s, const float2* __restrict__ tw, int tid, bool inverse) {
+  // in-place decimation-in-time on bit-reversed input; 512 butterflies per stage, 2 per thread
+  for (int len = 2; len <= SG_N; len <<= 1) {
+    const int half = len >> 1, step = SG_N / len;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int b = tid + 256 * r;
+      const int grp = b / half, k = b - grp * half;
+      const int i0 = grp * len + k, i1 = i0 + half;
+      float2 w = tw[k * step];
+      if (inverse) w.y = -w.y;
+      const float2 a = s[i0], c = s[i1];
+      const float2 t = make_float2(c.x * w.x - c.y * w.y, c.x * w.y + c.y * w.x);
+      s[i0] = make_float2(a.x + t.x, a.y + t.y);
+      s[i1] = make_float2(a.x - t.x, a.y - t.y);
+    }
+    __syncthreads();
+  }
+}
+
+// One block per (frame, clip).  pad = 0 (noise profile pass) or SG_PAD (signal pass).
+// Writes dB = 20 log10(|X| + eps) and optionally X.
+__global__ __launch_bounds__(256) void sg_stft_kernel(const float* __restrict__ y, long stride, const int* __restrict__ n_samples,
+                                                      const int* __restrict__ n_frames, int pad, const float2* __restrict__ tw,
+                                                      const float* __restrict__ win, float* __restrict__ db, float2* __restrict__ X,
+                                                      long clip_stride_rows) {
+  __shared__ float2 s[SG_N];
+  const int clip = blockIdx.y, fr = blockIdx.x, tid = threadIdx.x;
+  if (fr >= n_frames[clip]) return;
+  const int n = n_samples[clip];
+  const float* x = y + (long)clip * stride;
+  const long base = (long)fr * SG_HOP - SG_N / 2 - pad;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = tid + 256 * r;
+    const long o = base + i;
+    const float v = (o >= 0 && o < n) ? x[o] * win[i] * (1.0f / 512.0f) : 0.f;
+    s[__brev((unsigned)i) >> 22] = make_float2(v, 0.f);
+  }
+  __syncthreads();
+  fft1024(s, tw, tid, false);
+  const long row = (long)clip * clip_stride_rows + fr;
+  for (int b = tid; b < SG_BINS; b += 256) {
+    const float2 v = s[b];
+    db[row * SG_LD + b] = 20.0f * log10f(sqrtf(v.x * v.x + v.y * v.y) + 2.220446049250313e-16f);
+    if (X) X[row * SG_LD + b] = v;
+  }
+}
+
+// Per (clip, bin): max over frames; then (noise pass) mean/std of max(dB, max-80) -> thresh, or
+// (signal pass) floor = max - 80.  Block = 32 bins x 8 frame groups, coalesced along bins.
+__global__ __launch_bounds__(256) void sg_bin_stats_kernel(const float* __restrict__ db, const int* __restrict__ n_frames,
+                                                           long clip_stride_rows, float n_std, float* __restrict__ thresh,
+                                                           float* __restrict__ floor_out) {
+  __shared__ float red[8][32];
+  const int clip = blockIdx.y, bl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int b = blockIdx.x * 32 + bl;
+  const int nf = n_frames[clip];
+  const float* p = db + (long)clip * clip_stride_rows * SG_LD + b;
+  const bool live = b < SG_BINS;
+  float mx = -INFINITY;
+  if (live) for (int f = grp; f < nf; f += 8) mx = fmaxf(mx, p[(long)f * SG_LD]);
+  red[grp][bl] = mx;
+  __syncthreads();
+  mx = red[0][bl];
+#pragma unroll
+  for (int g = 1; g < 8; g++) mx = fmaxf(mx, red[g][bl]);
+  const float fl = mx - 80.0f;
+  __syncthreads();
+  if (floor_out) {
+    if (live && grp == 0) floor_out[clip * SG_LD + b] = fl;
+    return;
+  }
+  float s = 0.f;
+  if (live) for (int f = grp; f < nf; f += 8) s += fmaxf(p[(long)f * SG_LD], fl);
+  red[grp][bl] = s;
+  __syncthreads();
+  s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; g++) s += red[g][bl];
+  const float mean = s / (float)nf;
+  __syncthreads();
+  float q = 0.f;
+  if (live) for (int f = grp; f < nf; f += 8) { const float d = fmaxf(p[(long)f * SG_LD], fl) - mean; q += d * d; }
+  red[grp][bl] = q;
+  __syncthreads();
+  q = 0.f;
+#pragma unroll
+  for (int g = 0; g < 8; g++) q += red[g][bl];
+  if (live && grp == 0) thresh[clip * SG_LD + b] = mean + n_std * sqrtf(q / (float)nf);
+}
+
+// mask (hard gate scaled by prop_decrease) convolved along bins with the 33-tap triangle
+__global__ void sg_mask_freq_kernel(const float* __restrict__ db, const float* __restrict__ floorv, const float* __restrict__ thresh,
+                                    const int* __restrict__ n_frames, long clip_stride_rows, float prop, const float* __restrict__ ff,
+                                    float* __restrict__ tmp) {
+  const int clip = blockIdx.z, fr = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fr >= n_frames[clip] || b >= SG_BINS) return;
+  const long row = ((long)clip * clip_stride_rows + fr) * SG_LD;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 33; i++) {
+    const int bb = b + i - 16;
+    if (bb >= 0 && bb < SG_BINS) {
+      const float v = fmaxf(db[row + bb], floorv[clip * SG_LD + bb]);
+      acc += ff[i] * (v > thresh[clip * SG_LD + bb] ? 1.0f : 1.0f - prop);
+    }
+  }
+  tmp[row + b] = acc;
+}
+
+// 7-tap triangle along frames, multiply the spectrum in place
+__global__ void sg_mask_time_apply_kernel(const float* __restrict__ tmp, const int* __restrict__ n_frames, long clip_stride_rows,
+                                          const float* __restrict__ ft, float2* __restrict__ X) {
+  const int clip = blockIdx.z, fr = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = n_frames[clip];
+  if (fr >= nf || b >= SG_BINS) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 7; j++) {
+    const int f2 = fr + j - 3;
+    if (f2 >= 0 && f2 < nf) acc += ft[j] * tmp[((long)clip * clip_stride_rows + f2) * SG_LD + b];
+  }
+  const long idx = ((long)clip * clip_stride_rows + fr) * SG_LD + b;
+  const float2 v = X[idx];
+  X[idx] = make_float2(v.x * acc, v.y * acc);
+}
+
+// inverse FFT of one masked frame -> windowed time-domain frame [1024]
+__global__ __launch_bounds__(256) void sg_istft_kernel(const float2* __restrict__ X, const int* __restrict__ n_frames,
+                                                       long clip_stride_rows, const float2* __restrict__ tw, const float* __restrict__ win,
+                                                       float* __restrict__ td) {
+  __shared__ float2 s[SG_N];
+  const int clip = blockIdx.y, fr = blockIdx.x, tid = threadIdx.x;
+  if (fr >= n_frames[clip]) return;
+  const long row = (long)clip * clip_stride_rows + fr;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = tid + 256 * r;
+    float2 v;
+    if (i <= 512) v = X[row * SG_LD + i];
+    else { v = X[row * SG_LD + (SG_N - i)]; v.y = -v.y; }   // Hermitian extension of the one-sided spectrum
+    if (i == 0 || i == 512) v.y = 0.f;
+    s[__brev((unsigned)i) >> 22] = v;
+  }
+  __syncthreads();
+  fft1024(s, tw, tid, true);
+  // irfft scaling 1/N times sum(win) = 512 ("spectrum" scaling undone), then the synthesis window
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int i = tid + 256 * r;
+    td[row * SG_N + i] = s[i].x * (512.0f / 1024.0f) * win[i];
+  }
+}
+
+// overlap-add, divide by the overlap-added squared window, crop the zero padding away
+__global__ void sg_overlap_add_kernel(const float* __restrict__ td, const int* __restrict__ n_samples, const int* __restrict__ n_frames,
+                                      long clip_stride_rows, const float* __restrict__ win, float* __restrict__ out, long stride) {
+  const int clip = blockIdx.y;
+  const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_samples[clip];
+  if (o >= stride) return;
+  float v = 0.f;
+  if (o < n) {
+    const int nf = n_frames[clip];
+    const long t_out = o + SG_PAD;                 // index in the istft output (boundary already removed)
+    if (t_out < (long)(nf - 1) * SG_HOP) {
+      const long q = t_out + SG_N / 2;             // index in the boundary-extended signal
+      const int j_hi = (int)(q / SG_HOP);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int j = j_hi - d;
+        const long i = q - (long)j * SG_HOP;
+        if (j >= 0 && j < nf && i < SG_N) {
+          num += td[((long)clip * clip_stride_rows + j) * SG_N + i];
+          den += win[i] * win[i];
+        }
+      }
+      v = den > 1e-10f ? num / den : num;
+    }
+  }
+  out[(long)clip * stride + o] = v;
+}
+
+}  // namespace
+
+struct ccx_specgate {
+  ccx_ctx* ctx = nullptr;
+  int max_clips = 0;
+  long max_samples = 0, rows = 0;  // rows = frame capacity per clip
+  std::vector<void*> allocs;
+  float2* tw = nullptr; float* win = nullptr; float* ff = nullptr; float* ft = nullptr;
+  float *db = nullptr, *tmp = nullptr, *td = nullptr, *thresh = nullptr, *floorv = nullptr;
+  float2* X = nullptr;
+  int *n_dev = nullptr, *nf_noise = nullptr, *nf_sig = nullptr;
+};
+
+namespace {
+template <typename T>
+int galloc(ccx_specgate* g, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = ccx_align(count * sizeof(T), 256);
+  CCX_HIP(g->ctx, hipMalloc(&p, bytes));
+  CCX_HIP(g->ctx, hipMemset(p, 0, bytes));
+  g->allocs.push_back(p);
+  *out = (T*)p;
+  return CCX_OK;
+}
+#define GTRY(expr)        \
+  do {                    \
+    int _rc = (expr);     \
+    if (_rc) return _rc;  \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+int ccx_specgate_create(ccx_ctx* ctx, int64_t max_samples, int max_clips, int sample_rate, ccx_specgate** out) {
+  if (!ctx) return CCX_ERR_ARG;
+  CCX_REQUIRE(ctx, out && max_clips >= 1 && max_samples >= 1, "ccx_specgate_create: bad arguments");
+  CCX_REQUIRE(ctx, max_samples <= 600000, "specgate: clips longer than one 600000-sample chunk are not supported (hot path feeds <= 30 s)");
+  CCX_REQUIRE(ctx, sample_rate == 16000, "specgate: smoothing widths are built for 16 kHz");
+  ccx_specgate* g = new ccx_specgate();
+  g->ctx = ctx; g->max_clips = max_clips; g->max_samples = max_samples;
+  g->rows = (max_samples + 2 * SG_PAD) / SG_HOP + 2;
+  std::vector<float2> tw(512);
+  std::vector<float> win(SG_N), ff(33), ft(7);
+  for (int k = 0; k < 512; k++) { const double a = -2.0 * M_PI * k / SG_N; tw[k] = make_float2((float)cos(a), (float)sin(a)); }
+  for (int i = 0; i < SG_N; i++) win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / SG_N));
+  // triangular ramps of noisereduce's _smoothing_filter: n_grad_freq = int(500 / (sr / 512)) = 16, n_grad_time = int(50 / 16) = 3
+  auto tri = [](int n, float* dst) {
+    std::vector<double> v;
+    for (int i = 0; i < n + 1; i++) v.push_back((double)i / (n + 1));            // linspace(0,1,n+1,endpoint=False)
+    for (int i = 0; i < n + 2; i++) v.push_back(1.0 - (double)i / (n + 1));        // linspace(1,0,n+2)
+    double s = 0;
+    for (size_t i = 1; i + 1 < v.size(); i++) s += v[i];
+    for (size_t i = 1; i + 1 < v.size(); i++) dst[i - 1] = (float)(v[i] / s);
+  };
+  tri(16, ff.data());
+  tri(3, ft.data());
+  GTRY(galloc(g, &g->tw, 512)); GTRY(galloc(g, &g->win, SG_N)); GTRY(galloc(g, &g->ff, 33)); GTRY(galloc(g, &g->ft, 7));
+  CCX_HIP(ctx, hipMemcpy(g->tw, tw.data(), 512 * 8, hipMemcpyHostToDevice));
+  CCX_HIP(ctx, hipMemcpy(g->win, win.data(), SG_N * 4, hipMemcpyHostToDevice));
+  CCX_HIP(ctx, hipMemcpy(g->ff, ff.data(), 33 * 4, hipMemcpyHostToDevice));
+  CCX_HIP(ctx, hipMemcpy(g->ft, ft.data(), 7 * 4, hipMemcpyHostToDevice));
+  const size_t R = (size_t)g->rows * max_clips;
+  GTRY(galloc(g, &g->db, R * SG_LD)); GTRY(galloc(g, &g->tmp, R * SG_LD)); GTRY(galloc(g, &g->X, R * SG_LD));
+  GTRY(galloc(g, &g->td, R * SG_N));
+  GTRY(galloc(g, &g->thresh, (size_t)max_clips * SG_LD)); GTRY(galloc(g, &g->floorv, (size_t)max_clips * SG_LD));
+  GTRY(galloc(g, &g->n_dev, (size_t)max_clips)); GTRY(galloc(g, &g->nf_noise, (size_t)max_clips)); GTRY(galloc(g, &g->nf_sig, (size_t)max_clips));
+  *out = g;
+  return CCX_OK;
+}
+
+void ccx_specgate_destroy(ccx_specgate* g) {
+  if (!g) return;
+  for (void* p : g->allocs) hipFree(p);
+  delete g;
+}
+
+int ccx_specgate_reduce(ccx_specgate* g, const float* y, int64_t stride, const int* n_samples, int B, float prop_decrease,
+                        float* out, void* stream_) {
+  if (!g) return CCX_ERR_ARG;
+  ccx_ctx* ctx = g->ctx;
+  hipStream_t st = (hipStream_t)stream_;
+  CCX_REQUIRE(ctx, y && out && n_samples && B >= 1 && B <= g->max_clips, "specgate_reduce: bad arguments (B=%d, max %d)", B, g->max_clips);
+  std::vector<int> nfn(B), nfs(B);
+  int max_fn = 0, max_fs = 0;
+  for (int b = 0; b < B; b++) {
+    CCX_REQUIRE(ctx, n_samples[b] >= 1 && n_samples[b] <= stride && n_samples[b] <= g->max_samples, "specgate_reduce: clip %d has %d samples (capacity %ld)", b, n_samples[b], g->max_samples);
+    nfn[b] = 1 + n_samples[b] / SG_HOP;                      // scipy.signal.stft, boundary zeros, padded=False
+    nfs[b] = 1 + (n_samples[b] + 2 * SG_PAD) / SG_HOP;
+    max_fn = nfn[b] > max_fn ? nfn[b] : max_fn;
+    max_fs = nfs[b] > max_fs ? nfs[b] : max_fs;
+  }
+  CCX_HIP(ctx, hipMemcpyAsync(g->n_dev, n_samples, B * 4, hipMemcpyHostToDevice, st));
+  CCX_HIP(ctx, hipMemcpyAsync(g->nf_noise, nfn.data(), B * 4, hipMemcpyHostToDevice, st));
+  CCX_HIP(ctx, hipMemcpyAsync(g->nf_sig, nfs.data(), B * 4, hipMemcpyHostToDevice, st));
+  CCX_HIP(ctx, hipStreamSynchronize(st));
+  const long rows = g->rows;
+  // noise profile from the clip itself
+  hipLaunchKernelGGL(sg_stft_kernel, dim3(max_fn, B), dim3(256), 0, st, y, (long)stride, g->n_dev, g->nf_noise, 0, g->tw, g->win, g->db,
+                     (float2*)nullptr, rows);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), B), dim3(256), 0, st, g->db, g->nf_noise, rows, 1.5f, g->thresh,
+                     (float*)nullptr);
+  CCX_CHECK_LAUNCH(ctx);
+  // padded signal pass
+  hipLaunchKernelGGL(sg_stft_kernel, dim3(max_fs, B), dim3(256), 0, st, y, (long)stride, g->n_dev, g->nf_sig, SG_PAD, g->tw, g->win, g->db,
+                     g->X, rows);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), B), dim3(256), 0, st, g->db, g->nf_sig, rows, 0.f, (float*)nullptr,
+                     g->floorv);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_mask_freq_kernel, dim3(ccx_cdiv(SG_BINS, 128), max_fs, B), dim3(128), 0, st, g->db, g->floorv, g->thresh, g->nf_sig,
+                     rows, prop_decrease, g->ff, g->tmp);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_mask_time_apply_kernel, dim3(ccx_cdiv(SG_BINS, 128), max_fs, B), dim3(128), 0, st, g->tmp, g->nf_sig, rows, g->ft,
+                     g->X);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_istft_kernel, dim3(max_fs, B), dim3(256), 0, st, g->X, g->nf_sig, rows, g->tw, g->win, g->td);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_overlap_add_kernel, dim3(ccx_cdiv((int)stride, 256), B), dim3(256), 0, st, g->td, g->n_dev, g->nf_sig, rows, g->win,
+                     out, (long)stride);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+}  // extern "C"

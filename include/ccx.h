@@ -159,6 +159,15 @@ int ccx_speaker_embed(ccx_speaker* s, const float* wav_dev, const int64_t* offse
 int ccx_speaker_segment(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,
                         float* out_dev, int64_t out_capacity_rows, int* frames_out, void* stream);
 
+/* ---- stationary spectral-gate denoiser (replaces nr.reduce_noise(y=, sr=, stationary=True,
+ *      prop_decrease=), reference back/api.py:349 and 832-833) ---------------------------------------- */
+typedef struct ccx_specgate ccx_specgate;
+int ccx_specgate_create(ccx_ctx* ctx, int64_t max_samples, int max_clips, int sample_rate, ccx_specgate** out);
+void ccx_specgate_destroy(ccx_specgate* g);
+/* y_dev [B, stride] f32, n_samples host [B] -> out_dev [B, stride] f32 (samples past n_samples[b] are zero) */
+int ccx_specgate_reduce(ccx_specgate* g, const float* y_dev, int64_t stride, const int* n_samples, int B,
+                        float prop_decrease, float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

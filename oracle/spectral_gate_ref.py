@@ -1,0 +1,58 @@
+"""CPU restatement of `noisereduce.reduce_noise(y, sr, stationary=True, prop_decrease=p)` as the
+reference calls it (/root/reference/back/api.py:349 on profile crops, 832-833 on the whole clip).
+
+TEST INFRASTRUCTURE ONLY.  noisereduce is an un-pinned, un-vendored, un-installed dependency; this
+follows its published SpectralGateStationary from recollection [UPSTREAM-RECALL] and uses the same
+scipy.signal primitives it uses (scipy IS installed here).  **Parity unpinned** (no fixture exists).
+
+Defaults restated: n_fft = win_length = 1024, hop 256, n_std_thresh_stationary = 1.5,
+freq_mask_smooth_hz = 500, time_mask_smooth_ms = 50, chunk_size 600000, padding 30000, noise statistics
+from the signal itself (y_noise=None), clip_noise_stationary=True.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.signal import fftconvolve, istft, stft
+
+N_FFT = 1024
+HOP = 256
+PADDING = 30000
+CHUNK = 600000
+
+
+def _amp_to_db(x, top_db=80.0):
+    x_db = 20 * np.log10(np.abs(x) + np.finfo(np.float64).eps)
+    return np.maximum(x_db, np.max(x_db, axis=-1, keepdims=True) - top_db)
+
+
+def smoothing_filter(sr: int):
+    n_grad_freq = int(500 / (sr / (N_FFT / 2)))
+    n_grad_time = int(50 / ((HOP / sr) * 1000))
+    f = np.concatenate([np.linspace(0, 1, n_grad_freq + 1, endpoint=False), np.linspace(1, 0, n_grad_freq + 2)])[1:-1]
+    t = np.concatenate([np.linspace(0, 1, n_grad_time + 1, endpoint=False), np.linspace(1, 0, n_grad_time + 2)])[1:-1]
+    filt = np.outer(f, t)
+    return filt / np.sum(filt), f / f.sum(), t / t.sum()
+
+
+def reduce_noise(y: np.ndarray, sr: int = 16000, prop_decrease: float = 1.0, n_std: float = 1.5) -> np.ndarray:
+    y = np.asarray(y, dtype=np.float32).reshape(-1)
+    n = y.shape[0]
+    if n > CHUNK:
+        raise NotImplementedError("oracle covers single-chunk inputs (<= 600000 samples), which is all the hot path feeds")
+    noise = y[:CHUNK]
+    _, _, noise_stft = stft(noise, nfft=N_FFT, noverlap=N_FFT - HOP, nperseg=N_FFT, padded=False)
+    noise_db = _amp_to_db(noise_stft)
+    thresh = np.mean(noise_db, axis=1) + np.std(noise_db, axis=1) * n_std
+    padded = np.zeros(n + 2 * PADDING, dtype=np.float32)
+    padded[PADDING:PADDING + n] = y
+    _, _, sig_stft = stft(padded, nfft=N_FFT, noverlap=N_FFT - HOP, nperseg=N_FFT, padded=False)
+    sig_db = _amp_to_db(sig_stft)
+    mask = (sig_db > thresh[:, None]).astype(np.float64)
+    mask = mask * prop_decrease + np.ones_like(mask) * (1.0 - prop_decrease)
+    filt, _, _ = smoothing_filter(sr)
+    mask = fftconvolve(mask, filt, mode="same")
+    _, den = istft(sig_stft * mask, nfft=N_FFT, noverlap=N_FFT - HOP, nperseg=N_FFT)
+    out = np.zeros(n + 2 * PADDING, dtype=np.float64)
+    m = min(out.shape[0], den.shape[0])
+    out[:m] = den[:m]
+    return out[PADDING:PADDING + n].astype(np.float32)

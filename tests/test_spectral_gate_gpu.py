@@ -1,0 +1,46 @@
+"""-m gpu: stationary spectral gate through the C ABI vs oracle/spectral_gate_ref.py (scipy.signal).
+fp32 FFTs vs scipy's: a handful of time-frequency cells sit within rounding of the gate threshold
+and may flip, so the waveform tolerance is rel-L2 2e-3 rather than rounding level."""
+import numpy as np
+import pytest
+import torch
+
+from clearconverse_amd.audio import synthetic_clip
+from oracle.spectral_gate_ref import reduce_noise
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel(); b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("seconds,prop", [(30.0, 0.5), (3.7, 0.5), (0.75, 1.0), (9.0, 0.3)])
+def test_matches_oracle(ccx_ctx, seconds, prop):
+    from clearconverse_amd.denoise import SpectralGate
+    g = SpectralGate(max_samples=480000, max_clips=4, ctx=ccx_ctx)
+    try:
+        x = synthetic_clip(7, 30.0)[: int(seconds * 16000)]
+        got = g(x, 16000, prop)
+        ref = reduce_noise(x, 16000, prop)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.isfinite(got).all()
+        assert _rel(got, ref) < 2e-3, _rel(got, ref)
+    finally:
+        g.close()
+
+
+def test_batch_equals_single_and_pads_zero(ccx_ctx):
+    from clearconverse_amd.denoise import SpectralGate
+    g = SpectralGate(max_samples=200000, max_clips=4, ctx=ccx_ctx)
+    try:
+        a = synthetic_clip(1, 30.0)[:100000]
+        b = synthetic_clip(2, 30.0)[:64000]
+        host = np.zeros((2, 100000), dtype=np.float32)
+        host[0] = a; host[1, :64000] = b
+        out = g.reduce_batch(torch.from_numpy(host).cuda(), [100000, 64000], 0.5).cpu().numpy()
+        assert np.array_equal(out[1, :64000], g(b, 16000, 0.5))
+        assert np.all(out[1, 64000:] == 0)
+    finally:
+        g.close()
