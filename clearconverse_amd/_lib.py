@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ccx_prof_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _fp]),
     "ccx_gemm_bf16": (_i, [_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "ccx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ccx_peak_normalize": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _vp]),
     "ccx_enc_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ccx_whisper_create": (_i, [_vp, C.POINTER(WhisperDims), _i, C.POINTER(_vp)]),
     "ccx_whisper_destroy": (None, [_vp]),
@@ -73,7 +74,7 @@ PROTOTYPES = {
     "ccx_speaker_destroy": (None, [_vp]),
     "ccx_speaker_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i64]),
     "ccx_speaker_finalize": (_i, [_vp]),
-    "ccx_speaker_embed": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _vp]),
+    "ccx_speaker_embed": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64p, _ip, _vp, _vp]),
     "ccx_speaker_segment": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64, _ip, _vp]),
     "ccx_specgate_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
     "ccx_specgate_destroy": (None, [_vp]),

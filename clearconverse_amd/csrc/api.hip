@@ -99,6 +99,11 @@ int ccx_layernorm(ccx_ctx* ctx, const float* x, const float* gamma, const float*
   return ccx_launch_layernorm(ctx, x, D, gamma, beta, (bf16_t*)out_bf16, out_f32, D, M, D, eps, (hipStream_t)stream);
 }
 
+int ccx_peak_normalize(ccx_ctx* ctx, const float* x, float* y, int64_t stride, const int* n_samples_dev, int B, float eps, void* stream) {
+  if (!ctx) return CCX_ERR_ARG;
+  return ccx_launch_peak_normalize(ctx, x, y, (long)stride, n_samples_dev, B, eps, (hipStream_t)stream);
+}
+
 int ccx_enc_attention(ccx_ctx* ctx, const void* q, const void* k, const void* vt, void* o, int B, int H, int S, int Spad,
                       void* stream) {
   if (!ctx) return CCX_ERR_ARG;

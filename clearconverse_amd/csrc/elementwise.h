@@ -8,3 +8,5 @@ int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* ga
 // dst_bf16[i] = bf16(src_f32[i])
 int ccx_launch_f32_to_bf16(ccx_ctx* ctx, const float* src, bf16_t* dst, long n, hipStream_t stream);
 int ccx_launch_fill_u16(ccx_ctx* ctx, bf16_t* dst, bf16_t v, long n, hipStream_t stream);
+int ccx_launch_peak_normalize(ccx_ctx* ctx, const float* x, float* y, long stride, const int* n_samples_dev, int B, float eps,
+                              hipStream_t stream);

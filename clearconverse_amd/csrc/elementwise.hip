@@ -71,6 +71,34 @@ __global__ void fill_u16_kernel(bf16_t* dst, bf16_t v, long n) {
   for (; i < n; i += stride) dst[i] = v;
 }
 
+// K3 peak normalisation: y[b][:n_b] = x / (max|x| + eps); eps == 0 -> divide only when the peak is > 0
+// (the two flavours of reference back/api.py:834 and 350-351).  One block per row, two passes.
+__global__ __launch_bounds__(1024) void peak_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, long stride,
+                                                              const int* __restrict__ n_samples, float eps) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = n_samples[b];
+  const float* xr = x + (long)b * stride;
+  float* yr = y + (long)b * stride;
+  float m = 0.f;
+  for (int i = tid; i < n; i += 1024) m = fmaxf(m, fabsf(xr[i]));
+  m = wave_reduce_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < 16; w++) m = fmaxf(m, red[w]);
+  const float inv = (eps > 0.f) ? 1.0f / (m + eps) : (m > 0.f ? 1.0f / m : 1.0f);
+  for (int i = tid; i < n; i += 1024) yr[i] = xr[i] * inv;
+}
+
+int ccx_launch_peak_normalize(ccx_ctx* ctx, const float* x, float* y, long stride, const int* n_samples_dev, int B, float eps,
+                              hipStream_t stream) {
+  CCX_REQUIRE(ctx, x && y && n_samples_dev && B >= 1, "peak_normalize: bad arguments");
+  hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, stream, x, y, stride, n_samples_dev, eps);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
 int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* gamma, const float* beta,
                          bf16_t* out_bf16, float* out_f32, long ldo, int M, int D, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);

@@ -134,19 +134,43 @@ __global__ __launch_bounds__(256) void pool_inorm_lrelu_kernel(const float* __re
   }
 }
 
-// mean || unbiased std over the crop's valid frames -> bf16 [n][ld] (mean at [0,C), std at [C,2C), zero pad)
+// mean || std over the crop's valid frames -> bf16 [n][ld] (mean at [0,C), std at [C,2C), zero pad).
+// Unweighted: unbiased std (StatsPool without weights).  Weighted (pyannote StatsPool with weights, used
+// for masked per-speaker embeddings in diarization): w_t = weights[nearest(t)], mean = sum(w x)/v1,
+// var = sum(w (x-mean)^2) / (v1 - v2/v1), v1 = sum w (+1e-8), v2 = sum w^2.
 __global__ __launch_bounds__(256) void stats_pool_kernel(const bf16_t* __restrict__ x, int ld_in, const int* __restrict__ row_off,
-                                                         const int* __restrict__ n_valid, bf16_t* __restrict__ out, int ld_out, int C) {
+                                                         const int* __restrict__ n_valid, const float* __restrict__ weights,
+                                                         const long* __restrict__ w_off, const int* __restrict__ w_len,
+                                                         bf16_t* __restrict__ out, int ld_out, int C) {
   const int crop = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const int n = n_valid[crop];
   const bf16_t* p = x + (long)row_off[crop] * ld_in + c;
-  float s = 0.f;
-  for (int t = 0; t < n; t++) s += bf16_to_f32(p[(long)t * ld_in]);
-  const float mean = s / (float)n;
-  float q = 0.f;
-  for (int t = 0; t < n; t++) { const float d = bf16_to_f32(p[(long)t * ld_in]) - mean; q += d * d; }
-  const float sd = sqrtf(q / (float)(n - 1));
+  float mean, sd;
+  if (weights == nullptr) {
+    float s = 0.f;
+    for (int t = 0; t < n; t++) s += bf16_to_f32(p[(long)t * ld_in]);
+    mean = s / (float)n;
+    float q = 0.f;
+    for (int t = 0; t < n; t++) { const float d = bf16_to_f32(p[(long)t * ld_in]) - mean; q += d * d; }
+    sd = sqrtf(q / (float)(n - 1));
+  } else {
+    const float* w = weights + w_off[crop];
+    const int nw = w_len[crop];
+    float v1 = 1e-8f, v2 = 0.f, s = 0.f;
+    for (int t = 0; t < n; t++) {
+      const float wt = w[(int)(((long)t * nw) / n)];   // F.interpolate(mode="nearest")
+      v1 += wt; v2 += wt * wt; s += wt * bf16_to_f32(p[(long)t * ld_in]);
+    }
+    mean = s / v1;
+    float q = 0.f;
+    for (int t = 0; t < n; t++) {
+      const float wt = w[(int)(((long)t * nw) / n)];
+      const float d = bf16_to_f32(p[(long)t * ld_in]) - mean;
+      q += wt * d * d;
+    }
+    sd = sqrtf(q / (v1 - v2 / v1 + 1e-8f));
+  }
   out[(long)crop * ld_out + c] = f32_to_bf16(mean);
   out[(long)crop * ld_out + C + c] = f32_to_bf16(sd);
 }
@@ -260,7 +284,7 @@ struct ccx_speaker {
   float2* ac = nullptr;
   float *s1 = nullptr, *c2 = nullptr, *c3 = nullptr, *acc = nullptr, *gx = nullptr, *logit = nullptr;
   bf16_t *s1n = nullptr, *s2n = nullptr, *s3n = nullptr, *a1 = nullptr, *a2 = nullptr, *a5 = nullptr, *pooled = nullptr, *hA = nullptr, *hB = nullptr;
-  long* crop_off = nullptr;
+  long* crop_off = nullptr; long* w_off = nullptr; int* w_len = nullptr;
   int *crop_len = nullptr, *off1 = nullptr, *off2 = nullptr, *off3 = nullptr, *nF1 = nullptr, *nF2 = nullptr, *nF3 = nullptr, *nFv = nullptr;
 };
 
@@ -498,7 +522,7 @@ int ccx_speaker_finalize(ccx_speaker* s) {
   const size_t R1 = (size_t)s->R1cap + 16, R2 = R1 / 3 + 16, R3 = R2 / 3 + 16, C = (size_t)s->max_crops;
   PTRY(palloc(s, &s->ac, C)); PTRY(palloc(s, &s->s1, R1 * 80)); PTRY(palloc(s, &s->s1n, R1 * 80 + 1024));
   PTRY(palloc(s, &s->c2, R1 * 128)); PTRY(palloc(s, &s->s2n, R2 * 64 + 1024)); PTRY(palloc(s, &s->c3, R2 * 128)); PTRY(palloc(s, &s->s3n, R3 * 64 + 1024));
-  PTRY(palloc(s, &s->crop_off, C)); PTRY(palloc(s, &s->crop_len, C));
+  PTRY(palloc(s, &s->crop_off, C)); PTRY(palloc(s, &s->crop_len, C)); PTRY(palloc(s, &s->w_off, C)); PTRY(palloc(s, &s->w_len, C));
   PTRY(palloc(s, &s->off1, C)); PTRY(palloc(s, &s->off2, C)); PTRY(palloc(s, &s->off3, C));
   PTRY(palloc(s, &s->nF1, C)); PTRY(palloc(s, &s->nF2, C)); PTRY(palloc(s, &s->nF3, C)); PTRY(palloc(s, &s->nFv, C));
   if (s->kind == 0) {
@@ -513,7 +537,8 @@ int ccx_speaker_finalize(ccx_speaker* s) {
 }
 
 // x-vector: wav_dev holds the crops at `offsets[i]` (in samples) with n_samples[i] each -> out_dev [n][512] f32
-int ccx_speaker_embed(ccx_speaker* s, const float* wav, const int64_t* offsets, const int* n_samples, int n, float* out, void* stream_) {
+int ccx_speaker_embed(ccx_speaker* s, const float* wav, const int64_t* offsets, const int* n_samples, int n, const float* weights,
+                      const int64_t* w_offsets, const int* w_lens, float* out, void* stream_) {
   if (!s) return CCX_ERR_ARG;
   ccx_ctx* ctx = s->ctx;
   hipStream_t st = (hipStream_t)stream_;
@@ -554,7 +579,16 @@ int ccx_speaker_embed(ccx_speaker* s, const float* wav, const int64_t* offsets, 
   p.A = dst; p.lda = 512; p.W = s->Wt[4]; p.ldw = 512; p.M = R3; p.N = 1500; p.K = 512; p.bias = s->bt[4]; p.out = s->a5; p.ldo = 1536;
   p.scale = s->sct[4]; p.shift = s->sht[4]; p.slope = 0.01f;
   PTRY(ccx_launch_gemm(ctx, EPI_BF16_LRELU_AFFINE, p, st));
-  hipLaunchKernelGGL(stats_pool_kernel, dim3(n, ccx_cdiv(1500, 256)), dim3(256), 0, st, s->a5, 1536, s->off3, s->nFv, s->pooled, 3072, 1500);
+  if (weights) {
+    CCX_REQUIRE(ctx, w_offsets && w_lens, "speaker_embed: weights need offsets and lengths");
+    std::vector<long> wo(n); std::vector<int> wl(n);
+    for (int i = 0; i < n; i++) { CCX_REQUIRE(ctx, w_lens[i] >= 1, "speaker_embed: empty weight row %d", i); wo[i] = w_offsets[i]; wl[i] = w_lens[i]; }
+    CCX_HIP(ctx, hipMemcpyAsync(s->w_off, wo.data(), n * sizeof(long), hipMemcpyHostToDevice, st));
+    CCX_HIP(ctx, hipMemcpyAsync(s->w_len, wl.data(), n * 4, hipMemcpyHostToDevice, st));
+    CCX_HIP(ctx, hipStreamSynchronize(st));
+  }
+  hipLaunchKernelGGL(stats_pool_kernel, dim3(n, ccx_cdiv(1500, 256)), dim3(256), 0, st, s->a5, 1536, s->off3, s->nFv, weights, s->w_off,
+                     s->w_len, s->pooled, 3072, 1500);
   CCX_CHECK_LAUNCH(ctx);
   // embedding Linear(3000 -> 512); out rows are 512 wide
   memset(&p, 0, sizeof(p));

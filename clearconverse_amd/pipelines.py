@@ -1,0 +1,298 @@
+"""VAD and speaker-diarization pipelines on top of the libccx networks.
+
+Drop-ins for `self.vad_pipeline(path)` and `self.diarization(path, min_speakers=, max_speakers=)`
+of the reference (Pipeline.from_pretrained("pyannote/voice-activity-detection") and
+("pyannote/speaker-diarization-3.1"), /root/reference/back/api.py:782-792; called at back/api.py:1311,
+1056-1060, 1124-1128).  Both return an `Annotation` whose `itertracks(yield_label=True)` yields
+(segment, track, label) with float `segment.start/.end` -- the only API the reference touches.
+
+The networks (SincNet/PyanNet segmentation, x-vector embedder) run in libccx; this module is the
+small host-side post-net (K22 in SURVEY.md): sliding windows, powerset decoding, overlap-add
+aggregation, hysteresis binarisation, agglomerative clustering, timeline reconstruction, restated from
+recollection of pyannote.audio 3.x [UPSTREAM-RECALL].  Deviations (also in DESIGN.md): the diarization
+pipeline embeds local speakers with the x-vector network instead of the bundled
+wespeaker ResNet-34 (not built yet), and hyper-parameters are the recalled values of the published
+pipeline configs, overridable through the constructors.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .audio import read_wav, resample_poly_sinc
+
+SR = 16000
+FRAME_STEP = 270 / SR          # SincNet: stride 10 x three maxpool3
+FRAME_DUR = 991 / SR           # receptive field of one output frame
+
+
+class Segment:
+    __slots__ = ("start", "end")
+
+    def __init__(self, start: float, end: float):
+        self.start, self.end = float(start), float(end)
+
+    @property
+    def duration(self):
+        return self.end - self.start
+
+    def __repr__(self):
+        return f"[{self.start:.3f} --> {self.end:.3f}]"
+
+
+class Annotation:
+    """Minimal stand-in for pyannote.core.Annotation (tracks sorted by start time)."""
+
+    def __init__(self, tracks: Sequence[Tuple[float, float, str]] = ()):
+        self._tracks = sorted(((float(s), float(e), str(l)) for s, e, l in tracks), key=lambda t: (t[0], t[1]))
+
+    def itertracks(self, yield_label: bool = False):
+        for i, (s, e, l) in enumerate(self._tracks):
+            yield (Segment(s, e), f"T{i}", l) if yield_label else (Segment(s, e), f"T{i}")
+
+    def labels(self):
+        return sorted({l for _, _, l in self._tracks})
+
+    def __len__(self):
+        return len(self._tracks)
+
+
+def load_mono_16k(path_or_wave) -> np.ndarray:
+    """The pipelines read the file themselves (raw, NOT denoised -- SURVEY.md section 3b)."""
+    if isinstance(path_or_wave, dict):
+        w = path_or_wave["waveform"]
+        x = w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)
+        sr = int(path_or_wave.get("sample_rate", SR))
+    else:
+        x, sr = read_wav(str(path_or_wave))
+    x = np.asarray(x, dtype=np.float32)
+    if x.ndim > 1:
+        x = x.mean(axis=0)
+    if sr != SR:
+        x = resample_poly_sinc(x[None], sr, SR)[0]
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def sliding_chunks(n: int, win: int, step: int) -> List[int]:
+    """Chunk start samples: every `step`, plus one final chunk (zero padded) covering the tail."""
+    if n <= win:
+        return [0]
+    starts = list(range(0, n - win + 1, step))
+    if starts[-1] + win < n:
+        starts.append(starts[-1] + step)
+    return starts
+
+
+def powerset_to_multilabel(logp: np.ndarray, n_spk: int = 3, max_set: int = 2) -> np.ndarray:
+    """[frames, 7] powerset log-probs -> hard [frames, 3] multi-label (argmax class -> its speaker set).
+    Class order: empty, {0}, {1}, {2}, {0,1}, {0,2}, {1,2}."""
+    sets: List[Tuple[int, ...]] = [()]
+    import itertools
+    for k in range(1, max_set + 1):
+        sets += list(itertools.combinations(range(n_spk), k))
+    table = np.zeros((len(sets), n_spk), dtype=np.float32)
+    for i, s in enumerate(sets):
+        table[i, list(s)] = 1.0
+    return table[np.argmax(logp, axis=-1)]
+
+
+def aggregate(chunks: Sequence[np.ndarray], starts: Sequence[int], n_samples: int, win: int) -> np.ndarray:
+    """Overlap-add average of per-chunk frame scores [frames, C] onto one global frame grid."""
+    C = chunks[0].shape[1]
+    n_out = int(np.ceil(n_samples / 270)) + 1
+    acc = np.zeros((n_out, C), dtype=np.float64)
+    cnt = np.zeros((n_out, 1), dtype=np.float64)
+    for sc, s0 in zip(chunks, starts):
+        f0 = int(round(s0 / 270))
+        f1 = min(n_out, f0 + sc.shape[0])
+        acc[f0:f1] += sc[: f1 - f0]
+        cnt[f0:f1] += 1
+    return (acc / np.maximum(cnt, 1)).astype(np.float32)
+
+
+def binarize(score: np.ndarray, onset: float, offset: float, min_on: float = 0.0, min_off: float = 0.0,
+             frame_step: float = FRAME_STEP, t0: float = 0.5 * FRAME_DUR) -> List[Tuple[float, float]]:
+    """Hysteresis thresholding of a 1-D frame score (pyannote Binarize): on above `onset`, off below `offset`;
+    then fill gaps < min_off and drop regions < min_on.  Frame i is centred at t0 + i*frame_step."""
+    regions: List[Tuple[float, float]] = []
+    active, start = False, 0.0
+    times = t0 + frame_step * np.arange(score.shape[0])
+    for t, y in zip(times, score):
+        if active:
+            if y < offset:
+                regions.append((start, float(t)))
+                active = False
+        elif y > onset:
+            start, active = float(t), True
+    if active:
+        regions.append((start, float(times[-1])))
+    merged: List[Tuple[float, float]] = []
+    for s, e in regions:
+        if merged and s - merged[-1][1] < min_off:
+            merged[-1] = (merged[-1][0], e)
+        else:
+            merged.append((s, e))
+    return [(s, e) for s, e in merged if e - s >= min_on and e > s]
+
+
+class VoiceActivityDetection:
+    """pyannote/voice-activity-detection: multi-label segmentation (sigmoid, 3 speakers), 5 s windows with
+    10 % step, max over speakers, overlap-add average, hysteresis binarisation."""
+
+    def __init__(self, seg_net, duration: float = 5.0, step_ratio: float = 0.1, onset: float = 0.767, offset: float = 0.377,
+                 min_duration_on: float = 0.136, min_duration_off: float = 0.067, batch: int = 64):
+        self.net = seg_net
+        self.win, self.step = int(duration * SR), int(duration * step_ratio * SR)
+        self.onset, self.offset, self.min_on, self.min_off, self.batch = onset, offset, min_duration_on, min_duration_off, batch
+
+    def speech_score(self, x: np.ndarray) -> np.ndarray:
+        starts = sliding_chunks(len(x), self.win, self.step)
+        dev = torch.from_numpy(x).to(self.net.device)
+        crops = []
+        for s in starts:
+            c = dev[s:s + self.win]
+            if c.numel() < self.win:
+                c = torch.nn.functional.pad(c, (0, self.win - c.numel()))
+            crops.append(c)
+        outs = []
+        for i in range(0, len(crops), self.batch):
+            outs += [o.cpu().numpy() for o in self.net.segment_batch(crops[i:i + self.batch])]
+        sc = [o.max(axis=-1, keepdims=True) if self.net.n_classes > 1 else o for o in outs]
+        if self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
+            sc = [1.0 - np.exp(o[:, :1]) for o in outs]
+        return aggregate(sc, starts, len(x), self.win)[:, 0]
+
+    def __call__(self, path_or_wave) -> Annotation:
+        x = load_mono_16k(path_or_wave)
+        if len(x) < 991 * 4:
+            return Annotation([])
+        score = self.speech_score(x)
+        n_valid = min(len(score), int(len(x) / 270))
+        regions = binarize(score[:n_valid], self.onset, self.offset, self.min_on, self.min_off)
+        dur = len(x) / SR
+        return Annotation([(max(0.0, s), min(dur, e), "SPEECH") for s, e in regions if min(dur, e) > max(0.0, s)])
+
+
+def agglomerative_centroid(emb: np.ndarray, threshold: float, min_cluster_size: int, min_clusters: int, max_clusters: int) -> np.ndarray:
+    """pyannote AgglomerativeClustering (centroid linkage on unit-normalised embeddings, euclidean): cut at
+    `threshold`, keep clusters with >= min_cluster_size members as "large", re-assign the rest to the nearest
+    large centroid, then force the number of clusters into [min_clusters, max_clusters]."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    n = emb.shape[0]
+    if n == 1:
+        return np.zeros(1, dtype=np.int64)
+    e = emb / np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)
+    Z = linkage(e, method="centroid", metric="euclidean")
+    lab = fcluster(Z, threshold, criterion="distance") - 1
+    sizes = np.bincount(lab)
+    big = min(min_cluster_size, max(1, n // 4))
+    large = [c for c in range(len(sizes)) if sizes[c] >= big]
+    if not large:
+        large = [int(np.argmax(sizes))]
+    if len(large) > max_clusters:
+        large = sorted(large, key=lambda c: -sizes[c])[:max_clusters]
+    elif len(large) < min_clusters:
+        # centroid linkage is not monotonic, so "maxclust = k" may return fewer than k clusters: grow the
+        # request until at least min_clusters come out, then keep the min_clusters largest
+        for m in range(min_clusters, n + 1):
+            lab = fcluster(Z, m, criterion="maxclust") - 1
+            sizes = np.bincount(lab)
+            if np.count_nonzero(sizes) >= min(min_clusters, n):
+                break
+        large = sorted([c for c in range(len(sizes)) if sizes[c] > 0], key=lambda c: -sizes[c])[:min_clusters]
+    cents = np.stack([e[lab == c].mean(axis=0) for c in large])
+    d = ((e[:, None, :] - cents[None, :, :]) ** 2).sum(-1)
+    return np.argmin(d, axis=1).astype(np.int64)
+
+
+class SpeakerDiarization:
+    """pyannote/speaker-diarization-3.1 shape: powerset segmentation over 10 s windows (10 % step), one
+    embedding per (window, local speaker) from overlap-free frames, agglomerative clustering, per-frame
+    speaker count x clustered activations -> timeline."""
+
+    def __init__(self, seg_net, embedder, duration: float = 10.0, step_ratio: float = 0.1, threshold: float = 0.7045654963945799,
+                 min_cluster_size: int = 12, min_duration_off: float = 0.0, min_active_ratio: float = 0.2, batch: int = 32):
+        self.net, self.emb = seg_net, embedder
+        self.win, self.step = int(duration * SR), int(duration * step_ratio * SR)
+        self.threshold, self.min_cluster_size, self.min_off, self.min_active, self.batch = threshold, min_cluster_size, min_duration_off, min_active_ratio, batch
+
+    def __call__(self, path_or_wave, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+                 num_speakers: Optional[int] = None) -> Annotation:
+        x = load_mono_16k(path_or_wave)
+        dur = len(x) / SR
+        if len(x) < 991 * 4:
+            return Annotation([])
+        lo = num_speakers or min_speakers or 1
+        hi = num_speakers or max_speakers or 20
+        starts = sliding_chunks(len(x), self.win, self.step)
+        dev = torch.from_numpy(x).to(self.net.device)
+        crops = []
+        for s in starts:
+            c = dev[s:s + self.win]
+            if c.numel() < self.win:
+                c = torch.nn.functional.pad(c, (0, self.win - c.numel()))
+            crops.append(c)
+        seg = []
+        for i in range(0, len(crops), self.batch):
+            seg += [o.cpu().numpy() for o in self.net.segment_batch(crops[i:i + self.batch])]
+        multi = [powerset_to_multilabel(o) if self.net.powerset else (o > 0.5).astype(np.float32) for o in seg]   # [frames, 3]
+        count = np.rint(aggregate([m.sum(axis=-1, keepdims=True) for m in multi], starts, len(x), self.win)[:, 0]).astype(np.int64)
+        count = np.minimum(count, hi)
+        # one embedding per sufficiently active (chunk, local speaker); prefer frames where it speaks alone
+        keys, e_crops, e_weights = [], [], []
+        for ci, m in enumerate(multi):
+            alone = (m.sum(axis=-1) == 1)
+            for sp in range(m.shape[1]):
+                act = m[:, sp] > 0
+                if act.mean() < self.min_active:
+                    continue
+                clean = act & alone
+                w = clean if clean.sum() >= 0.5 * act.sum() else act
+                keys.append((ci, sp))
+                e_crops.append(crops[ci])
+                e_weights.append(torch.from_numpy(w.astype(np.float32)))
+        if not keys:
+            return Annotation([])
+        embs = []
+        for i in range(0, len(e_crops), self.batch):
+            embs.append(self.emb.embed_batch(e_crops[i:i + self.batch], weights=e_weights[i:i + self.batch]).cpu().numpy())
+        embs = np.concatenate(embs, axis=0)
+        ok = np.isfinite(embs).all(axis=1)
+        labels = np.full(len(keys), -1, dtype=np.int64)
+        if ok.any():
+            labels[ok] = agglomerative_centroid(embs[ok], self.threshold, self.min_cluster_size, lo, hi)
+        n_clusters = int(labels.max()) + 1
+        if n_clusters <= 0:
+            return Annotation([])
+        # clustered activations per chunk, overlap-add averaged
+        clustered = []
+        for ci, m in enumerate(multi):
+            act = np.zeros((m.shape[0], n_clusters), dtype=np.float32)
+            for (kc, sp), lab in zip(keys, labels):
+                if kc == ci and lab >= 0:
+                    act[:, lab] = np.maximum(act[:, lab], m[:, sp])
+            clustered.append(act)
+        agg = aggregate(clustered, starts, len(x), self.win)          # [frames, clusters]
+        n_valid = min(agg.shape[0], int(len(x) / 270))
+        agg, count = agg[:n_valid], count[:n_valid]
+        # to_diarization: at each frame the `count` most active clusters speak
+        order = np.argsort(-agg, axis=1)
+        binary = np.zeros_like(agg)
+        for t in range(n_valid):
+            for r in range(min(count[t], n_clusters)):
+                if agg[t, order[t, r]] > 0:
+                    binary[t, order[t, r]] = 1.0
+        tracks = []
+        first_seen = {}
+        for c in range(n_clusters):
+            regs = binarize(binary[:, c], 0.5, 0.5, 0.0, self.min_off)
+            for s, e in regs:
+                s, e = max(0.0, s - 0.5 * FRAME_STEP), min(dur, e + 0.5 * FRAME_STEP)
+                if e > s:
+                    tracks.append((s, e, c))
+                    first_seen[c] = min(first_seen.get(c, 1e9), s)
+        rename = {c: f"SPEAKER_{i:02d}" for i, c in enumerate(sorted(first_seen, key=lambda c: first_seen[c]))}
+        return Annotation([(s, e, rename[c]) for s, e, c in tracks])

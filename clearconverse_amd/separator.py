@@ -20,6 +20,7 @@ class SepformerSeparator:
         if not torch.cuda.is_available():
             raise _lib.CcxError("SepformerSeparator needs a ROCm GPU: the HIP path has no CPU fallback")
         self.dims = dims
+        self.max_tokens, self.max_utts = int(max_tokens) // dims.segment * dims.segment, int(max_utts)
         self.device = torch.device("cuda", device)
         self.ctx = ctx or _lib.Context(device)
         self.lib = self.ctx.lib
@@ -32,6 +33,12 @@ class SepformerSeparator:
             t = t.detach().to("cpu", torch.float32).contiguous()
             self.ctx.check(self.lib.ccx_sepformer_set_tensor(self.handle, name.encode(), t.data_ptr(), t.numel()), f"set_tensor({name})")
         self.ctx.check(self.lib.ccx_sepformer_finalize(self.handle), "ccx_sepformer_finalize")
+
+    def tokens_for(self, n_samples: int) -> int:
+        """Encoder frames of one utterance after padding to whole chunks (capacity accounting)."""
+        d = self.dims
+        L = (int(n_samples) - d.kernel) // d.stride + 1
+        return (L + (d.segment - L % d.segment))
 
     def close(self):
         if getattr(self, "handle", None):

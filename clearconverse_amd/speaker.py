@@ -69,16 +69,23 @@ class XVectorEmbedder(_SpeakerNet):
     def __init__(self, state_dict, max_crops: int = 256, max_samples: int = 16000 * 600, device: int = 0, ctx=None):
         super().__init__(0, state_dict, 0, True, max_crops, max_samples, device, ctx)
 
-    def embed_batch(self, crops: Sequence) -> torch.Tensor:
-        """crops: list of 1-D waveforms (16 kHz) -> [n, 512] f32 tensor on the GPU."""
+    def embed_batch(self, crops: Sequence, weights: Optional[Sequence] = None) -> torch.Tensor:
+        """crops: list of 1-D waveforms (16 kHz) -> [n, 512] f32 tensor on the GPU.  `weights`
+        (optional): one 1-D frame-weight vector per crop (any resolution) for weighted statistics pooling."""
         out = torch.empty(len(crops), self.DIM, device=self.device, dtype=torch.float32)
+        i64p, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int)
         for i0 in range(0, len(crops), self.max_crops):
             part = crops[i0:i0 + self.max_crops]
             buf, offs, lens = self._pack(part)
             o = out[i0:i0 + len(part)]
-            self.ctx.check(self.lib.ccx_speaker_embed(self.handle, buf.data_ptr(), offs.ctypes.data_as(C.POINTER(C.c_int64)),
-                                                      lens.ctypes.data_as(C.POINTER(C.c_int)), len(part), o.data_ptr(),
-                                                      _lib.current_stream_ptr()), "ccx_speaker_embed")
+            if weights is None:
+                wptr, woffs, wlens = None, None, None
+            else:
+                wbuf, wo, wl = self._pack(weights[i0:i0 + self.max_crops])
+                wptr, woffs, wlens = wbuf.data_ptr(), wo.ctypes.data_as(i64p), wl.ctypes.data_as(ip)
+            self.ctx.check(self.lib.ccx_speaker_embed(self.handle, buf.data_ptr(), offs.ctypes.data_as(i64p), lens.ctypes.data_as(ip),
+                                                      len(part), wptr, woffs, wlens, o.data_ptr(), _lib.current_stream_ptr()),
+                           "ccx_speaker_embed")
         return out
 
     def __call__(self, item: dict) -> np.ndarray:
@@ -96,6 +103,7 @@ class SegmentationNet(_SpeakerNet):
                  max_samples: int = 16000 * 600, device: int = 0, ctx=None):
         super().__init__(1, state_dict, n_classes, powerset, max_crops, max_samples, device, ctx)
         self.n_classes = n_classes
+        self.powerset = bool(powerset)
 
     def segment_batch(self, crops: Sequence) -> List[torch.Tensor]:
         outs: List[torch.Tensor] = []

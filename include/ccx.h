@@ -54,6 +54,12 @@ int ccx_gemm_bf16(ccx_ctx* ctx, int epi, const void* A_dev, int64_t lda, const v
 int ccx_layernorm(ccx_ctx* ctx, const float* x_dev, const float* gamma_dev, const float* beta_dev,
                   void* out_bf16_dev, float* out_f32_dev, int M, int D, float eps, void* stream);
 
+/* Peak normalisation y = x / (max|x| + eps) per row (eps == 0: only when the peak is > 0) -- replaces
+ * `signal_np / (np.max(np.abs(signal_np)) + 1e-8)` (reference back/api.py:834) and lines 350-351.
+ * x,y [B, stride] f32 (may alias), n_samples_dev [B] int32 on the device. */
+int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t stride, const int* n_samples_dev, int B,
+                       float eps, void* stream);
+
 /* Non-causal attention, head_dim 64 (Whisper encoder).  q,k: [B*H, Spad, 64] bf16 with rows >= S
  * zero; vt: [B*H, 64, Spad] bf16; o: [B*S, H*64] bf16.  Softmax scale 1/8 (= 64^-0.25 on q and k). */
 int ccx_enc_attention(ccx_ctx* ctx, const void* q_dev, const void* k_dev, const void* vt_dev, void* o_dev,
@@ -151,9 +157,11 @@ void ccx_speaker_destroy(ccx_speaker* s);
  * "linear.0.weight", "classifier.weight". */
 int ccx_speaker_set_tensor(ccx_speaker* s, const char* name, const float* data, int64_t numel);
 int ccx_speaker_finalize(ccx_speaker* s);
-/* n crops stored in wav_dev at sample offsets[i], n_samples[i] long (host arrays) -> out_dev [n, 512] f32 */
+/* n crops stored in wav_dev at sample offsets[i], n_samples[i] long (host arrays) -> out_dev [n, 512] f32.
+ * weights_dev (optional, NULL = plain mean/std pooling): per-crop frame weights at any resolution
+ * (w_lens[i] values at w_offsets[i]), nearest-interpolated to the pooling frames (pyannote StatsPool). */
 int ccx_speaker_embed(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,
-                      float* out_dev, void* stream);
+                      const float* weights_dev, const int64_t* w_offsets, const int* w_lens, float* out_dev, void* stream);
 /* per-frame class scores of n crops, concatenated in crop order: out_dev [sum frames, n_classes] f32;
  * frames_out[i] (host) = frames of crop i. */
 int ccx_speaker_segment(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,

@@ -93,16 +93,25 @@ TDNN_K = [5, 3, 3, 1, 1]
 TDNN_DIL = [1, 2, 3, 1, 1]
 
 
-def xvector_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor) -> torch.Tensor:
-    """XVectorSincNet.forward for ONE crop (Inference(window="whole")): wav [1, T] -> [512]."""
+def xvector_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """XVectorSincNet.forward for ONE crop (Inference(window="whole")): wav [1, T] -> [512].
+    weights [n_w] (optional): StatsPool frame weights, nearest-interpolated to the pooled frames."""
     x = sincnet_forward(sd, wav[None])
     for i, (k, dil) in enumerate(zip(TDNN_K, TDNN_DIL)):
         x = F.conv1d(x, sd[f"tdnns.{i}.0.weight"].float(), sd[f"tdnns.{i}.0.bias"].float(), dilation=dil)
         x = F.leaky_relu(x)
         x = F.batch_norm(x, sd[f"tdnns.{i}.2.running_mean"].float(), sd[f"tdnns.{i}.2.running_var"].float(),
                          sd[f"tdnns.{i}.2.weight"].float(), sd[f"tdnns.{i}.2.bias"].float(), training=False, eps=1e-5)
-    mean = x.mean(dim=-1)
-    std = x.std(dim=-1, unbiased=True)
+    if weights is None:
+        mean = x.mean(dim=-1)
+        std = x.std(dim=-1, unbiased=True)
+    else:
+        w = F.interpolate(weights.float().view(1, 1, -1), size=x.shape[-1], mode="nearest")   # [1,1,frames]
+        v1 = w.sum(dim=2) + 1e-8
+        mean = torch.sum(x * w, dim=2) / v1
+        v2 = torch.square(w).sum(dim=2)
+        var = torch.sum(torch.square(x - mean.unsqueeze(2)) * w, dim=2) / (v1 - v2 / v1 + 1e-8)
+        std = torch.sqrt(var)
     pooled = torch.cat([mean, std], dim=-1)
     return F.linear(pooled, sd["embedding.weight"].float(), sd["embedding.bias"].float())[0]
 

@@ -1,0 +1,55 @@
+"""CPU: the host-side post-net of the VAD / diarization pipelines (numpy), on hand-checkable inputs."""
+import numpy as np
+
+from clearconverse_amd import pipelines as P
+
+
+def test_sliding_chunks_cover_the_signal():
+    assert P.sliding_chunks(100, 160, 16) == [0]
+    s = P.sliding_chunks(480000, 160000, 16000)
+    assert s[0] == 0 and s[-1] + 160000 >= 480000 and all(b - a == 16000 for a, b in zip(s, s[1:]))
+    s = P.sliding_chunks(170001, 160000, 16000)
+    assert s == [0, 16000]
+
+
+def test_powerset_decoding():
+    lp = np.full((4, 7), -10.0, dtype=np.float32)
+    lp[0, 0] = 0; lp[1, 2] = 0; lp[2, 4] = 0; lp[3, 6] = 0      # empty, {1}, {0,1}, {1,2}
+    m = P.powerset_to_multilabel(lp)
+    assert m.tolist() == [[0, 0, 0], [0, 1, 0], [1, 1, 0], [0, 1, 1]]
+
+
+def test_aggregate_is_an_overlap_average():
+    a = np.ones((10, 1), dtype=np.float32); b = 3 * np.ones((10, 1), dtype=np.float32)
+    out = P.aggregate([a, b], [0, 5 * 270], 15 * 270, 10 * 270)
+    assert np.allclose(out[:5, 0], 1) and np.allclose(out[5:10, 0], 2) and np.allclose(out[10:15, 0], 3)
+
+
+def test_binarize_hysteresis_and_duration_rules():
+    y = np.array([0, .9, .6, .5, .3, .2, .9, .9, 0, 0, .9, 0], dtype=np.float32)
+    r = P.binarize(y, onset=0.8, offset=0.4, frame_step=1.0, t0=0.0)
+    assert r == [(1.0, 4.0), (6.0, 8.0), (10.0, 11.0)]
+    r = P.binarize(y, 0.8, 0.4, min_on=1.5, min_off=0.0, frame_step=1.0, t0=0.0)
+    assert r == [(1.0, 4.0), (6.0, 8.0)]
+    r = P.binarize(y, 0.8, 0.4, min_on=0.0, min_off=2.5, frame_step=1.0, t0=0.0)
+    assert r == [(1.0, 11.0)]
+
+
+def test_agglomerative_clustering_respects_speaker_bounds():
+    rng = np.random.default_rng(0)
+    a = rng.normal(0, 0.05, (20, 16)) + np.eye(16)[0] * 3
+    b = rng.normal(0, 0.05, (20, 16)) + np.eye(16)[1] * 3
+    c = rng.normal(0, 0.05, (3, 16)) + np.eye(16)[2] * 3
+    e = np.concatenate([a, b, c])
+    lab = P.agglomerative_centroid(e, threshold=0.7, min_cluster_size=5, min_clusters=1, max_clusters=2)
+    assert len(set(lab)) == 2 and len(set(lab[:20])) == 1 and len(set(lab[20:40])) == 1 and lab[0] != lab[20]
+    lab3 = P.agglomerative_centroid(e, threshold=0.7, min_cluster_size=2, min_clusters=1, max_clusters=20)
+    assert len(set(lab3)) == 3
+    one = P.agglomerative_centroid(e, threshold=5.0, min_cluster_size=2, min_clusters=2, max_clusters=2)
+    assert len(set(one)) == 2
+
+
+def test_annotation_contract():
+    ann = P.Annotation([(2.0, 3.0, "SPEAKER_01"), (0.5, 1.5, "SPEAKER_00")])
+    got = [(seg.start, seg.end, lab) for seg, _, lab in ann.itertracks(yield_label=True)]
+    assert got == [(0.5, 1.5, "SPEAKER_00"), (2.0, 3.0, "SPEAKER_01")]

@@ -56,6 +56,22 @@ def test_xvector_matches_oracle_ragged(ccx_ctx):
         m.close()
 
 
+def test_xvector_weighted_pooling(ccx_ctx):
+    from clearconverse_amd.speaker import XVectorEmbedder
+    sd = synthetic_xvector_state_dict(seed=5)
+    m = XVectorEmbedder(sd, max_crops=4, max_samples=16000 * 25, ctx=ccx_ctx)
+    try:
+        crops = _crops([160000, 160000])
+        g = torch.Generator().manual_seed(0)
+        w = [(torch.rand(589, generator=g) > 0.5).float(), torch.rand(293, generator=g)]
+        got = m.embed_batch(crops, weights=w).cpu()
+        for i in range(2):
+            ref = P.xvector_forward(sd, crops[i][None], weights=w[i])
+            assert _rel(got[i], ref) < 2e-2, (i, _rel(got[i], ref))
+    finally:
+        m.close()
+
+
 def test_xvector_rejects_short_crop(ccx_ctx):
     from clearconverse_amd._lib import CcxError
     from clearconverse_amd.speaker import XVectorEmbedder
