@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- xRT (audio-seconds / wall-second) of the MI355X-native ClearConverse hot path.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload pipeline|whisper] [--batch B]
 
-One "step" = one pass of the hot path over one batch of synthetic 30 s / 16 kHz clips that are
-already resident in HBM: log-mel -> Whisper small.en encoder -> greedy
-decode (<= 224 tokens, hipGraph-captured step chain).  Workload at N=1 is BASELINE.json configs[1]
-("Whisper small.en encoder+greedy-decode only, batch=8x30 s clips") until the separator and the
-speaker nets land; it is named in config.workload.  N>1: one process per GPU (torchrun), clips are
-sharded across ranks with no data-path collective (weak scaling); the only collectives are the
-timing barrier/max and one all-gather of the token records at the end of the timed region.
+One "step" = one pass of the hot path over one batch of synthetic 30 s / 16 kHz clips already resident
+in HBM.
+  * workload `pipeline` (default; BASELINE.json configs[3], the configuration the metric is quoted on):
+    full VAD -> diarize -> separate -> transcribe pass over B=32 clips per GPU through
+    clearconverse_amd.batch.BatchPipeline (every model call batched across clips; control flow pinned to
+    the synthetic schedule because seeded random weights give arbitrary diarization / EOT -- stated in
+    `config.schedule`; VAD and diarization are still computed).
+  * workload `whisper` (configs[1]): log-mel -> small.en encoder -> greedy decode of 8 x 30 s clips.
+N>1: one process per GPU under torchrun, clips sharded across ranks (clip i -> rank i mod N) with no
+data-path collective; the only collectives are the timing barrier/max and one all-gather of the token
+records at the end (weak scaling: B clips per GPU).
 
-The JSON line carries `roofline` for the dominant kernel (per-launch HIP-event timing recorded by
-libccx over the timed steps) and `cpu_baseline` (oracle/whisper_ref.py, fp32 torch on the host
-cores, bounded sample) -- see DESIGN.md "Measurement".
+The JSON line carries `roofline` for the dominant eagerly launched kernel (per-launch HIP events recorded
+by libccx on the launch stream over the timed steps) and `cpu_baseline` (oracle/, fp32 on the host
+cores, bounded sample, rank 0 at N=1 only) -- DESIGN.md "Measurement".
 """
 import argparse
 import json
@@ -30,6 +34,7 @@ import torch
 
 PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
+MFMA_KERNELS = ("gemm_bf16_nt_kernel", "enc_attention_kernel")
 
 
 def enc_flops_per_window(d):
@@ -40,9 +45,16 @@ def enc_flops_per_window(d):
     return enc, cross
 
 
-def cpu_baseline(dims, sd, clip, rules, threads, tokens):
-    """Oracle (CPU restatement of the reference path, fp32 torch) on ONE 30 s clip: log-mel +
-    encoder + `tokens` greedy steps with KV cache.  Returns audio-seconds per wall-second."""
+def decode_bytes_per_step(d, B):
+    """Algorithmic HBM bytes of one decode step: bf16 decoder weights + tied embedding once, plus each
+    sequence's cross-attention K/V."""
+    D, L = d.n_text_state, d.n_text_layer
+    w = 2 * (L * (4 * D * D + 2 * D * 4 * D + 4 * D * D) + d.n_vocab * D)   # self (qkv+o) + mlp + cross (q,o + k,v not re-read) + logits
+    kv = B * L * 2 * d.n_audio_ctx * D * 2
+    return w + kv
+
+
+def cpu_baseline_whisper(dims, sd, clip, rules, threads, tokens):
     from oracle import whisper_ref as R
     torch.set_num_threads(threads)
     orc = R.WhisperRef(R.Dims(**dims.__dict__), sd)
@@ -51,18 +63,52 @@ def cpu_baseline(dims, sd, clip, rules, threads, tokens):
     with torch.no_grad():
         mel = R.pad_or_trim(R.log_mel_spectrogram(torch.from_numpy(clip))[:, : len(clip) // 160], 3000)
         xa = orc.encode(mel[None])
+        t_enc = time.perf_counter() - t0
         r = R.greedy_decode_cached(orc, xa, [rules.sot], orules, sample_len=tokens)
     dt = time.perf_counter() - t0
-    return len(clip) / 16000.0 / dt, dt, len(r.tokens)
+    return dict(t_enc=t_enc, t_tok=(dt - t_enc) / max(1, len(r.margins)), total=dt, n_tok=len(r.tokens))
+
+
+def cpu_baseline_pipeline(models_sd, clip, rules, threads):
+    """Oracle op timings on bounded samples, scaled by the op counts of ONE 30 s clip under the pinned
+    schedule (6 Whisper calls x (encode + 224 tokens), 4 separator regions (18 s), 107.6 s of x-vector input
+    + 63 x 10 s diarization crops, 51 x 5 s VAD + 21 x 10 s segmentation chunks, 58 s through the gate)."""
+    from oracle import pyannote_ref as P, sepformer_ref as S, spectral_gate_ref as G, whisper_ref as R
+    torch.set_num_threads(threads)
+    wd, wsd, sdims, ssd, xsd, psd = models_sd
+    w = cpu_baseline_whisper(wd, wsd, clip[: 16000 * 6], rules, threads, tokens=24)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        S.SepformerRef(S.SepDims(**sdims.__dict__), ssd).separate(torch.from_numpy(clip[None, : 16000 * 2]))
+        t_sep_per_s = (time.perf_counter() - t0) / 2.0
+        t0 = time.perf_counter()
+        for _ in range(4):
+            P.xvector_forward(xsd, torch.from_numpy(clip[None, : 12800]))
+        t_xvec_per_s = (time.perf_counter() - t0) / (4 * 0.8)
+        osd = dict(psd); osd["powerset"] = torch.tensor(1)
+        t0 = time.perf_counter()
+        P.pyannet_forward(osd, torch.from_numpy(clip[None, None, : 16000 * 5]))
+        t_seg_per_s = (time.perf_counter() - t0) / 5.0
+    t0 = time.perf_counter()
+    G.reduce_noise(clip, 16000, 0.5)
+    t_gate_per_s = (time.perf_counter() - t0) / 30.0
+    t_clip = (6 * (w["t_enc"] + 224 * w["t_tok"]) + 18.0 * t_sep_per_s + (107.6 + 630.0) * t_xvec_per_s
+              + (51 * 5 + 21 * 10) * t_seg_per_s + 58.0 * t_gate_per_s)
+    sample = (f"timed samples (fp32 torch/scipy oracle): 1 Whisper window encode {w['t_enc']:.1f} s + 24 greedy tokens "
+              f"({w['t_tok'] * 1e3:.0f} ms/token), 2 s separator, 4 x 0.8 s x-vector, 5 s PyanNet, 30 s spectral gate; "
+              f"scaled by one clip's op counts under the pinned schedule -> {t_clip:.0f} s per 30 s clip")
+    return 30.0 / t_clip, sample
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="30 s clips per GPU per step")
+    ap.add_argument("--workload", choices=("pipeline", "whisper"), default="pipeline")
+    ap.add_argument("--batch", type=int, default=None, help="30 s clips per GPU per step (default 32 pipeline / 8 whisper)")
     ap.add_argument("--sample-len", type=int, default=224)
+    ap.add_argument("--whisper-group", type=int, default=96, help="sequences decoded together in the pipeline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -79,32 +125,43 @@ def main():
 
     from clearconverse_amd import _lib
     from clearconverse_amd.audio import synthetic_clip
+    from clearconverse_amd.batch import BatchPipeline, gather_transcripts
     from clearconverse_amd.tokenizer import DecodeRules
-    from clearconverse_amd.weights import WhisperDims, find_whisper_checkpoint, synthetic_whisper_state_dict
-    from clearconverse_amd.whisper import WhisperModel
+    from clearconverse_amd.weights import (SepDims, WhisperDims, find_whisper_checkpoint, synthetic_pyannet_state_dict,
+                                           synthetic_sepformer_state_dict, synthetic_whisper_state_dict, synthetic_xvector_state_dict)
 
-    B = args.batch
-    ck = find_whisper_checkpoint("small.en")
-    if ck is not None:
-        dims, sd = ck
-        weights = "checkpoint"
-    else:
-        dims, sd = WhisperDims.small_en(), synthetic_whisper_state_dict(WhisperDims.small_en(), seed=0)
-        weights = "synthetic-seed0"
-    ctx = _lib.Context(local_rank)
-    model = WhisperModel(dims, sd, max_batch=B, device=local_rank, ctx=ctx)
+    pipeline = args.workload == "pipeline"
+    B = args.batch or (32 if pipeline else 8)
     rules = DecodeRules()
+    ctx = _lib.Context(local_rank)
+    ck = find_whisper_checkpoint("small.en")
+    weights = "checkpoint" if ck is not None else "synthetic-seed0"
+    dims = ck[0] if ck is not None else WhisperDims.small_en()
 
     # clip i of the global corpus -> rank i % world; B clips per rank
     clips = [synthetic_clip(rank + world * i, 30.0) for i in range(B)]
-    n = [len(c) for c in clips]
     audio = torch.from_numpy(np.stack(clips)).cuda(local_rank).contiguous()   # resident in HBM before timing
-    prompts = [[rules.sot] for _ in range(B)]
 
-    def step():
-        model.log_mel(audio, n)
-        model.encode(B)
-        return model.decode_greedy(prompts, sample_len=args.sample_len)
+    if pipeline:
+        from clearconverse_amd.models import load_models
+        models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0)
+        sd = None
+        bp = BatchPipeline(models, whisper_group=args.whisper_group, sample_len=args.sample_len)
+
+        def step():
+            return bp.run_pinned(audio)
+    else:
+        from clearconverse_amd.whisper import WhisperModel
+        sd = ck[1] if ck is not None else synthetic_whisper_state_dict(dims, seed=0)
+        model = WhisperModel(dims, sd, max_batch=B, device=local_rank, ctx=ctx)
+        n = [len(c) for c in clips]
+        prompts = [[rules.sot] for _ in range(B)]
+
+        def step():
+            model.log_mel(audio, n)
+            model.encode(B)
+            recs = model.decode_greedy(prompts, sample_len=args.sample_len)
+            return dict(records=recs, tokens=sum(len(r["tokens"]) for r in recs), whisper_calls=B)
 
     for _ in range(args.warmup):
         step()
@@ -114,10 +171,12 @@ def main():
     torch.cuda.synchronize()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
-    n_tokens = 0
+    n_tokens = n_calls = 0
+    res = None
     for _ in range(args.steps):
         res = step()
-        n_tokens += sum(len(r["tokens"]) for r in res)
+        n_tokens += res["tokens"]
+        n_calls += res["whisper_calls"]
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -130,15 +189,11 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # transcripts (token ids) gathered on every rank: the one data-path collective (C2)
-        rec = torch.full((B, args.sample_len), rules.eot, dtype=torch.int32, device="cuda")
-        for b, r in enumerate(res):
-            rec[b, : len(r["tokens"])] = torch.tensor(r["tokens"], dtype=torch.int32)
-        gathered = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)
-        tk = torch.tensor([n_tokens], device="cuda", dtype=torch.int64)
-        dist.all_reduce(tk)
-        n_tokens = int(tk.item())
+        gathered = gather_transcripts(res["records"], args.sample_len, rules.eot, torch.device("cuda", local_rank))   # C2
+        cnt = torch.tensor([n_tokens, n_calls], device="cuda", dtype=torch.int64)
+        dist.all_reduce(cnt)
+        n_tokens, n_calls = int(cnt[0]), int(cnt[1])
+        assert gathered.shape[0] == len(res["records"]) * world
 
     audio_s = 30.0 * B * world * args.steps
     value = audio_s / dt
@@ -150,29 +205,49 @@ def main():
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += by; a[3] += ms
         roof = None
-        if agg:
-            name = max(agg, key=lambda k: agg[k][3])
-            cnt, fl, by, ms = agg[name]
-            if name in ("gemm_bf16_nt_kernel", "enc_attention_kernel"):
+        priced = {k: v for k, v in agg.items() if v[1] > 0 or v[2] > 0}
+        if priced:
+            name = max(priced, key=lambda k: priced[k][3])
+            cnt_, fl, by, ms = priced[name]
+            if name in MFMA_KERNELS:
                 ach = fl / (ms * 1e-3) / 1e12
                 roof = dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=None, launches=cnt,
-                            avg_launch_us=round(ms * 1e3 / cnt, 2), flops_per_launch=fl / cnt)
+                            frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=None, launches=cnt_,
+                            avg_launch_us=round(ms * 1e3 / cnt_, 2), flops_per_launch=fl / cnt_)
             else:
                 ach = by / (ms * 1e-3) / 1e9
                 roof = dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, launches=cnt,
-                            avg_launch_us=round(ms * 1e3 / cnt, 2), bytes_per_launch=by / cnt)
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, launches=cnt_,
+                            avg_launch_us=round(ms * 1e3 / cnt_, 2), bytes_per_launch=by / cnt_)
         stage_ms = {k: round(v[3] / args.steps, 3) for k, v in agg.items()}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             threads = min(os.cpu_count() or 1, 32)
-            xrt, secs, ntok = cpu_baseline(dims, sd, clips[0], rules, threads, tokens=args.sample_len)
-            cpu = dict(value=round(xrt, 3), unit="xRT (audio-sec/wall-sec)", cores=threads, kind="port",
-                       sample=f"1 x 30 s clip: log-mel + small.en encoder + {ntok}-token greedy decode, fp32 torch, {secs:.1f} s")
+            if pipeline:
+                sdims = SepDims()
+                msd = (dims, ck[1] if ck is not None else synthetic_whisper_state_dict(dims, seed=0), sdims,
+                       synthetic_sepformer_state_dict(sdims, seed=1), synthetic_xvector_state_dict(seed=2),
+                       synthetic_pyannet_state_dict(7, seed=3))
+                xrt, sample = cpu_baseline_pipeline(msd, clips[0], rules, threads)
+            else:
+                w = cpu_baseline_whisper(dims, sd, clips[0], rules, threads, tokens=args.sample_len)
+                xrt = 30.0 / w["total"]
+                sample = f"1 x 30 s clip: log-mel + small.en encoder + {w['n_tok']}-token greedy decode, fp32 torch, {w['total']:.1f} s"
+            cpu = dict(value=round(xrt, 3), unit="xRT (audio-sec/wall-sec)", cores=threads, kind="port", sample=sample)
 
         enc_f, cross_f = enc_flops_per_window(dims)
+        cfg = {"workload": "full_pipeline_vad_diarize_separate_transcribe (BASELINE configs[3])" if pipeline
+               else "whisper_small_en_logmel_encode_greedy_decode (BASELINE configs[1])",
+               "clips_per_gpu": B, "clip_seconds": 30, "sample_len": args.sample_len, "whisper_calls": n_calls,
+               "tokens_decoded": n_tokens, "parallelism": f"clip-sharded x{world}",
+               "encoder_gflop_per_window": round((enc_f + cross_f) / 1e9, 1)}
+        if pipeline:
+            cfg["schedule"] = ("pinned synthetic schedule (SURVEY.md 8d): per clip 2 regular + 2 overlap-bearing segments -> "
+                               "6 Whisper windows, 4 separator regions, 62 x-vector crops + diarization crops, VAD and "
+                               "diarization computed but not steering")
+            cfg["whisper_group"] = args.whisper_group
+            cfg["stage_ms_per_step"] = {k: round(v / (args.steps + args.warmup), 2) for k, v in bp.stage_ms.items()} if bp.stage_ms else None
         out = {
             "metric": "xRT (audio-sec/wall-sec) end-to-end, 30 s 16 kHz clips",
             "value": round(value, 2),
@@ -186,10 +261,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": f"synthetic clips (seed 1234+i), weights {weights}, greedy T=0",
-            "config": {"workload": "whisper_small_en_logmel_encode_greedy_decode (BASELINE configs[1])",
-                       "clips_per_gpu": B, "clip_seconds": 30, "sample_len": args.sample_len,
-                       "tokens_decoded": n_tokens, "parallelism": f"clip-sharded x{world}",
-                       "encoder_gflop_per_window": round((enc_f + cross_f) / 1e9, 1)},
+            "config": cfg,
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": stage_ms,

@@ -175,6 +175,11 @@ class BatchPipeline:
                     vad_regions=n_vad, diar_turns=n_diar, records=reg_txt + ov_txt, sims=[float(s) for s in sims], window_sims=len(win_sims))
 
 
+def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:
+    """clip i -> rank i mod world: independent units, no data-path collective."""
+    return [i for i in range(n_clips) if i % world == rank]
+
+
 def gather_transcripts(records: List[dict], sample_len: int, eot: int, device) -> Optional[torch.Tensor]:
     """All-gather of fixed-size token records over RCCL (xGMI): the one data-path collective (C2)."""
     import torch.distributed as dist
