@@ -81,14 +81,10 @@ class BatchPipeline:
         den = self._peak(m["denoiser"].reduce_batch(audio, [N] * B, self.nra), [N] * B, 1e-8)
         t = self._mark("load_audio_gate", t, timed)
         # 2. VAD and diarization on the RAW clips (computed, not steering)
-        n_vad = n_diar = 0
-        for b in range(B):
-            item = {"waveform": audio[b], "sample_rate": SR}
-            n_vad += len(m["vad_pipeline"](item))
+        items = [{"waveform": audio[b], "sample_rate": SR} for b in range(B)]
+        n_vad = sum(len(a) for a in m["vad_pipeline"].batch(items))
         t = self._mark("vad", t, timed)
-        for b in range(B):
-            item = {"waveform": audio[b], "sample_rate": SR}
-            n_diar += len(m["diarization"](item, min_speakers=1, max_speakers=2))
+        n_diar = sum(len(a) for a in m["diarization"].batch(items, min_speakers=1, max_speakers=2))
         t = self._mark("diarization", t, timed)
         # 3. speaker profiles from the scheduled turns (all >= 0.75 s): gate each crop, normalise, embed (A8)
         sched = [(spk, int(s * SR), int(e * SR)) for spk, s, e in SCHEDULE_30S]
@@ -99,7 +95,7 @@ class BatchPipeline:
             buf[i, :n[i]] = c
         clean = self._peak(m["denoiser"].reduce_batch(buf, n, self.nra), n, 0.0)
         pe = m["embedding_model"].embed_batch([clean[i, :n[i]] for i in range(len(crops))])
-        var = torch.stack([torch.var(c) for c in crops])
+        var = torch.stack([torch.var(c) for c in crops])   # embedding quality = variance of the raw crop (reference 939)
         profiles = []
         for b in range(B):
             prof = {}
@@ -113,10 +109,10 @@ class BatchPipeline:
         reg = [(b, spk, s, e) for b in range(B) for spk, s, e in sched[2:]]
         reg_crops = [den[b, s:e] for b, _, s, e in reg]
         re_ = m["embedding_model"].embed_batch(reg_crops)
-        sims = [torch.nn.functional.cosine_similarity(re_[i], profiles[b][spk], dim=0) for i, (b, spk, _, _) in enumerate(reg)]
+        sims = torch.nn.functional.cosine_similarity(re_, torch.stack([profiles[b][spk] for b, spk, _, _ in reg]), dim=1)
         t = self._mark("segment_embed", t, timed)
-        reg_txt = self._whisper(reg_crops, [PROMPT_TWO_PEOPLE] * len(reg_crops))
-        t = self._mark("whisper_regular", t, timed)
+        # (their Whisper windows are decoded together with the overlap regions' at the end: the calls are independent,
+        #  and one large decode batch amortises the latency-bound step chain)
         # 5. overlap-bearing segments (A 0-9, B 7-16): sliding-window attribution (0.8 s / 0.4 s)
         ov = [(b, spk, s, e) for b in range(B) for spk, s, e in sched[:2]]
         wins, owner = [], []
@@ -127,11 +123,10 @@ class BatchPipeline:
                 owner.append(i)
                 pos += int(self.hop * SR)
         we = m["embedding_model"].embed_batch(wins)
-        win_sims = []
-        for j, i in enumerate(owner):
-            b = ov[i][0]
-            win_sims.append((float(torch.nn.functional.cosine_similarity(we[j], profiles[b]["A"], dim=0)),
-                             float(torch.nn.functional.cosine_similarity(we[j], profiles[b]["B"], dim=0))))
+        pa = torch.stack([profiles[ov[i][0]]["A"] for i in owner])
+        pb = torch.stack([profiles[ov[i][0]]["B"] for i in owner])
+        win_sims = torch.stack([torch.nn.functional.cosine_similarity(we, pa, dim=1),
+                                torch.nn.functional.cosine_similarity(we, pb, dim=1)], dim=1)   # [windows, 2], one launch
         t = self._mark("sliding_windows", t, timed)
         # scripted window labels: each overlap segment splits at the scheduled overlap (7-9 s) into two regions
         regions = []
@@ -161,18 +156,16 @@ class BatchPipeline:
         for k in range(2):
             srcs.append(self._peak(sep[:, :, k].contiguous(), rn, 1e-8))
         se = [m["embedding_model"].embed_batch([srcs[k][i, :rn[i]] for i in range(len(rcrops))]) for k in range(2)]
-        best = []
-        for i, (b, spk, _, _) in enumerate(regions):
-            s0 = torch.nn.functional.cosine_similarity(se[0][i], profiles[b][spk], dim=0)
-            s1 = torch.nn.functional.cosine_similarity(se[1][i], profiles[b][spk], dim=0)
-            k = 0 if s0 >= s1 else 1
-            best.append(srcs[k][i, :rn[i]])
+        pr = torch.stack([profiles[b][spk] for b, spk, _, _ in regions])
+        pick = (torch.nn.functional.cosine_similarity(se[1], pr, dim=1) > torch.nn.functional.cosine_similarity(se[0], pr, dim=1)).cpu().tolist()
+        best = [srcs[1 if pick[i] else 0][i, :rn[i]] for i in range(len(regions))]
         t = self._mark("source_select", t, timed)
-        ov_txt = self._whisper(best, [PROMPT_SINGLE] * len(best))
-        t = self._mark("whisper_overlap", t, timed)
+        all_txt = self._whisper(reg_crops + best, [PROMPT_TWO_PEOPLE] * len(reg_crops) + [PROMPT_SINGLE] * len(best))
+        reg_txt, ov_txt = all_txt[:len(reg_crops)], all_txt[len(reg_crops):]
+        t = self._mark("whisper", t, timed)
         return dict(n_clips=B, audio_seconds=30.0 * B, whisper_calls=len(reg_crops) + len(best), tokens=sum(len(r["tokens"]) for r in reg_txt + ov_txt),
                     embeds=len(crops) + len(reg_crops) + len(wins) + 2 * len(rcrops), separator_calls=len(rcrops),
-                    vad_regions=n_vad, diar_turns=n_diar, records=reg_txt + ov_txt, sims=[float(s) for s in sims], window_sims=len(win_sims))
+                    vad_regions=n_vad, diar_turns=n_diar, records=reg_txt + ov_txt, sims=sims.cpu().tolist(), window_sims=int(win_sims.shape[0]))
 
 
 def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:

@@ -24,8 +24,9 @@ struct DecLinearParams {
 int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams& p, hipStream_t stream);
 // number of grid.z K-slices ccx_launch_dec_linear will use (= number of partial slabs written)
 int ccx_dec_linear_ksplit(int K, int epi);
+// out = bf16 LayerNorm(x + sum pend); if x_out != null also writes the resolved x there (must not alias x)
 int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
-                              const float* b, bf16_t* out, int M, int K, float eps, hipStream_t stream);
+                              const float* b, bf16_t* out, float* x_out, int M, int K, float eps, hipStream_t stream);
 
 struct DecAttnParams {
   const float* q;       // [B][H][64] f32

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 // Stand-alone residual resolve + LayerNorm -> bf16 (input of the logits GEMV): one wave per row.
 __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __restrict__ x, const float* __restrict__ pend,
                                                              int pend_n, long pend_stride, const float* __restrict__ g,
-                                                             const float* __restrict__ b, bf16_t* __restrict__ out, int M,
-                                                             int K, float eps) {
+                                                             const float* __restrict__ b, bf16_t* __restrict__ out,
+                                                             float* __restrict__ x_out, int M, int K, float eps) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
     }
     if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
     v[i] = a;
+    if (x_out && idx < nv) ((float4*)(x_out + (long)m * K))[idx] = a;   // resolved residual stream (ping-pong buffer)
     sm += (a.x + a.y) + (a.z + a.w);
   }
   const float mean = wave_reduce_sum(sm) / (float)K;
@@ -343,10 +344,11 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
 }
 
 int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
-                              const float* b, bf16_t* out, int M, int K, float eps, hipStream_t stream) {
+                              const float* b, bf16_t* out, float* x_out, int M, int K, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, K % 4 == 0 && K <= 1024, "dec_resolve_ln: K=%d unsupported", K);
+  CCX_REQUIRE(ctx, x_out != x, "dec_resolve_ln: x_out must not alias x");
   hipLaunchKernelGGL(dec_resolve_ln_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, pend, pend_n, pend_stride, g, b,
-                     out, M, K, eps);
+                     out, x_out, M, K, eps);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }
@@ -407,6 +409,8 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
   if (act == ACT_COMBINE && epi == DEPI_PARTIAL) return launch_dec_linear_mt<1, ACT_COMBINE, DEPI_PARTIAL>(ctx, p, ksplit, stream);
   if (act == ACT_BF16 && epi == DEPI_PARTIAL) return launch_dec_linear_mt<1, ACT_BF16, DEPI_PARTIAL>(ctx, p, ksplit, stream);
   if (act == ACT_BF16 && epi == DEPI_F32) return launch_dec_linear_mt<1, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
+  if (act == ACT_BF16 && epi == DEPI_SELF_QKV) return launch_dec_linear_mt<1, ACT_BF16, DEPI_SELF_QKV>(ctx, p, 1, stream);
+  if (act == ACT_BF16 && epi == DEPI_BF16_GELU) return launch_dec_linear_mt<1, ACT_BF16, DEPI_BF16_GELU>(ctx, p, 1, stream);
   return ccx_fail(ctx, CCX_ERR_ARG, "dec_linear: unsupported act=%d epi=%d", act, epi);
 }
 

@@ -618,10 +618,19 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
                        DecLinearParams* extra) -> int {
     DecLinearParams lp;
     if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
-    lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias;
-    lp.x = cur; lp.pend = w->pend; lp.pend_n = pend_n; lp.pend_stride = pstride; lp.x_out = pend_n > 0 ? other : nullptr;
-    lp.ln_g = g; lp.ln_b = bta; lp.eps = 1e-5f; lp.out = out; lp.ldo = ldo;
-    int rc = ccx_launch_dec_linear(ctx, ACT_LN, epi, lp, stream);
+    lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias; lp.out = out; lp.ldo = ldo;
+    int rc;
+    if (B > 16) {
+      // many sequences: normalise ONCE in a stand-alone kernel instead of redundantly in every weight-panel block
+      rc = ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, g, bta, w->dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
+      if (rc) return rc;
+      lp.act = w->dxn; lp.lda = D;
+      rc = ccx_launch_dec_linear(ctx, ACT_BF16, epi, lp, stream);
+    } else {
+      lp.x = cur; lp.pend = w->pend; lp.pend_n = pend_n; lp.pend_stride = pstride; lp.x_out = pend_n > 0 ? other : nullptr;
+      lp.ln_g = g; lp.ln_b = bta; lp.eps = 1e-5f;
+      rc = ccx_launch_dec_linear(ctx, ACT_LN, epi, lp, stream);
+    }
     if (rc) return rc;
     if (pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
     return CCX_OK;
@@ -664,7 +673,7 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, w->dffn));
   }
   // resolve the last partials + final LN, then logits against the tied embedding
-  TRY(ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, w->lnd_g, w->lnd_b, w->dxn, B, D, 1e-5f, stream));
+  TRY(ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, w->lnd_g, w->lnd_b, w->dxn, nullptr, B, D, 1e-5f, stream));
   {
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));

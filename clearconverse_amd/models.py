@@ -51,8 +51,8 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
         "whisper_model": whisper,
         "separator": separator,
         "embedding_model": embedder,
-        "vad_pipeline": VoiceActivityDetection(seg_vad),
-        "diarization": SpeakerDiarization(seg_diar, embedder),
+        "vad_pipeline": VoiceActivityDetection(seg_vad, batch=max_crops),
+        "diarization": SpeakerDiarization(seg_diar, embedder, batch=max_crops),
         "denoiser": gate,
         "segmentation_vad": seg_vad,
         "segmentation_diar": seg_diar,

@@ -146,34 +146,56 @@ class VoiceActivityDetection:
                  min_duration_on: float = 0.136, min_duration_off: float = 0.067, batch: int = 64):
         self.net = seg_net
         self.win, self.step = int(duration * SR), int(duration * step_ratio * SR)
-        self.onset, self.offset, self.min_on, self.min_off, self.batch = onset, offset, min_duration_on, min_duration_off, batch
+        self.onset, self.offset, self.min_on, self.min_off, self.batch_size = onset, offset, min_duration_on, min_duration_off, batch
 
-    def speech_score(self, x: np.ndarray) -> np.ndarray:
+    def _chunks(self, x: np.ndarray):
         starts = sliding_chunks(len(x), self.win, self.step)
-        dev = torch.from_numpy(x).to(self.net.device)
+        dev = torch.from_numpy(x).to(self.net.device) if not torch.is_tensor(x) else x.to(self.net.device)
         crops = []
         for s in starts:
             c = dev[s:s + self.win]
             if c.numel() < self.win:
                 c = torch.nn.functional.pad(c, (0, self.win - c.numel()))
             crops.append(c)
-        outs = []
-        for i in range(0, len(crops), self.batch):
-            outs += [o.cpu().numpy() for o in self.net.segment_batch(crops[i:i + self.batch])]
-        sc = [o.max(axis=-1, keepdims=True) if self.net.n_classes > 1 else o for o in outs]
+        return starts, crops
+
+    def _score(self, outs, starts, n):
         if self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
             sc = [1.0 - np.exp(o[:, :1]) for o in outs]
-        return aggregate(sc, starts, len(x), self.win)[:, 0]
+        else:
+            sc = [o.max(axis=-1, keepdims=True) for o in outs]
+        return aggregate(sc, starts, n, self.win)[:, 0]
+
+    def batch(self, items: Sequence) -> List[Annotation]:
+        """Several files / waveforms at once: all windows of all items go through the network together."""
+        xs = [load_mono_16k(it) for it in items]
+        plans, crops = [], []
+        for x in xs:
+            if len(x) < 991 * 4:
+                plans.append(None)
+                continue
+            starts, cr = self._chunks(x)
+            plans.append((starts, len(crops), len(cr)))
+            crops += cr
+        outs = []
+        for i in range(0, len(crops), self.batch_size):
+            outs += self.net.segment_batch(crops[i:i + self.batch_size])
+        outs = [o.cpu().numpy() for o in outs]
+        anns = []
+        for x, pl in zip(xs, plans):
+            if pl is None:
+                anns.append(Annotation([]))
+                continue
+            starts, i0, n = pl
+            score = self._score(outs[i0:i0 + n], starts, len(x))
+            n_valid = min(len(score), int(len(x) / 270))
+            regions = binarize(score[:n_valid], self.onset, self.offset, self.min_on, self.min_off)
+            dur = len(x) / SR
+            anns.append(Annotation([(max(0.0, s), min(dur, e), "SPEECH") for s, e in regions if min(dur, e) > max(0.0, s)]))
+        return anns
 
     def __call__(self, path_or_wave) -> Annotation:
-        x = load_mono_16k(path_or_wave)
-        if len(x) < 991 * 4:
-            return Annotation([])
-        score = self.speech_score(x)
-        n_valid = min(len(score), int(len(x) / 270))
-        regions = binarize(score[:n_valid], self.onset, self.offset, self.min_on, self.min_off)
-        dur = len(x) / SR
-        return Annotation([(max(0.0, s), min(dur, e), "SPEECH") for s, e in regions if min(dur, e) > max(0.0, s)])
+        return self.batch([path_or_wave])[0]
 
 
 def agglomerative_centroid(emb: np.ndarray, threshold: float, min_cluster_size: int, min_clusters: int, max_clusters: int) -> np.ndarray:
@@ -217,49 +239,78 @@ class SpeakerDiarization:
                  min_cluster_size: int = 12, min_duration_off: float = 0.0, min_active_ratio: float = 0.2, batch: int = 32):
         self.net, self.emb = seg_net, embedder
         self.win, self.step = int(duration * SR), int(duration * step_ratio * SR)
-        self.threshold, self.min_cluster_size, self.min_off, self.min_active, self.batch = threshold, min_cluster_size, min_duration_off, min_active_ratio, batch
+        self.threshold, self.min_cluster_size, self.min_off, self.min_active, self.batch_size = threshold, min_cluster_size, min_duration_off, min_active_ratio, batch
 
     def __call__(self, path_or_wave, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
                  num_speakers: Optional[int] = None) -> Annotation:
-        x = load_mono_16k(path_or_wave)
-        dur = len(x) / SR
-        if len(x) < 991 * 4:
-            return Annotation([])
+        return self.batch([path_or_wave], min_speakers, max_speakers, num_speakers)[0]
+
+    def batch(self, items: Sequence, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+              num_speakers: Optional[int] = None) -> List[Annotation]:
+        """Several files / waveforms at once: segmentation windows and speaker-embedding crops of all items
+        are batched through the networks; clustering / reconstruction stay per item."""
         lo = num_speakers or min_speakers or 1
         hi = num_speakers or max_speakers or 20
-        starts = sliding_chunks(len(x), self.win, self.step)
-        dev = torch.from_numpy(x).to(self.net.device)
-        crops = []
-        for s in starts:
-            c = dev[s:s + self.win]
-            if c.numel() < self.win:
-                c = torch.nn.functional.pad(c, (0, self.win - c.numel()))
-            crops.append(c)
+        xs = [load_mono_16k(it) for it in items]
+        plans, crops = [], []
+        for x in xs:
+            if len(x) < 991 * 4:
+                plans.append(None)
+                continue
+            starts = sliding_chunks(len(x), self.win, self.step)
+            dev = torch.from_numpy(x).to(self.net.device)
+            cr = []
+            for s in starts:
+                c = dev[s:s + self.win]
+                if c.numel() < self.win:
+                    c = torch.nn.functional.pad(c, (0, self.win - c.numel()))
+                cr.append(c)
+            plans.append((starts, len(crops), len(cr)))
+            crops += cr
         seg = []
-        for i in range(0, len(crops), self.batch):
-            seg += [o.cpu().numpy() for o in self.net.segment_batch(crops[i:i + self.batch])]
-        multi = [powerset_to_multilabel(o) if self.net.powerset else (o > 0.5).astype(np.float32) for o in seg]   # [frames, 3]
-        count = np.rint(aggregate([m.sum(axis=-1, keepdims=True) for m in multi], starts, len(x), self.win)[:, 0]).astype(np.int64)
-        count = np.minimum(count, hi)
-        # one embedding per sufficiently active (chunk, local speaker); prefer frames where it speaks alone
-        keys, e_crops, e_weights = [], [], []
-        for ci, m in enumerate(multi):
-            alone = (m.sum(axis=-1) == 1)
-            for sp in range(m.shape[1]):
-                act = m[:, sp] > 0
-                if act.mean() < self.min_active:
-                    continue
-                clean = act & alone
-                w = clean if clean.sum() >= 0.5 * act.sum() else act
-                keys.append((ci, sp))
-                e_crops.append(crops[ci])
-                e_weights.append(torch.from_numpy(w.astype(np.float32)))
-        if not keys:
-            return Annotation([])
+        for i in range(0, len(crops), self.batch_size):
+            seg += self.net.segment_batch(crops[i:i + self.batch_size])
+        seg = [o.cpu().numpy() for o in seg]
+        # local speakers of every window of every item
+        per_item = []
+        e_crops, e_weights = [], []
+        for x, pl in zip(xs, plans):
+            if pl is None:
+                per_item.append(None)
+                continue
+            starts, i0, n = pl
+            multi = [powerset_to_multilabel(o) if self.net.powerset else (o > 0.5).astype(np.float32) for o in seg[i0:i0 + n]]
+            keys = []
+            for ci, m in enumerate(multi):
+                alone = (m.sum(axis=-1) == 1)
+                for sp in range(m.shape[1]):
+                    act = m[:, sp] > 0
+                    if act.mean() < self.min_active:
+                        continue
+                    clean = act & alone
+                    w = clean if clean.sum() >= 0.5 * act.sum() else act
+                    keys.append((ci, sp))
+                    e_crops.append(crops[i0 + ci])
+                    e_weights.append(torch.from_numpy(w.astype(np.float32)))
+            per_item.append((starts, multi, keys))
         embs = []
-        for i in range(0, len(e_crops), self.batch):
-            embs.append(self.emb.embed_batch(e_crops[i:i + self.batch], weights=e_weights[i:i + self.batch]).cpu().numpy())
-        embs = np.concatenate(embs, axis=0)
+        for i in range(0, len(e_crops), self.batch_size):
+            embs.append(self.emb.embed_batch(e_crops[i:i + self.batch_size], weights=e_weights[i:i + self.batch_size]).cpu().numpy())
+        embs = np.concatenate(embs, axis=0) if embs else np.zeros((0, 512), dtype=np.float32)
+        anns, e0 = [], 0
+        for x, it in zip(xs, per_item):
+            if it is None or not it[2]:
+                anns.append(Annotation([]))
+                continue
+            starts, multi, keys = it
+            anns.append(self._reconstruct(len(x), starts, multi, keys, embs[e0:e0 + len(keys)], lo, hi))
+            e0 += len(keys)
+        return anns
+
+    def _reconstruct(self, n_samples: int, starts, multi, keys, embs, lo: int, hi: int) -> Annotation:
+        dur = n_samples / SR
+        count = np.rint(aggregate([m.sum(axis=-1, keepdims=True) for m in multi], starts, n_samples, self.win)[:, 0]).astype(np.int64)
+        count = np.minimum(count, hi)
         ok = np.isfinite(embs).all(axis=1)
         labels = np.full(len(keys), -1, dtype=np.int64)
         if ok.any():
@@ -267,7 +318,6 @@ class SpeakerDiarization:
         n_clusters = int(labels.max()) + 1
         if n_clusters <= 0:
             return Annotation([])
-        # clustered activations per chunk, overlap-add averaged
         clustered = []
         for ci, m in enumerate(multi):
             act = np.zeros((m.shape[0], n_clusters), dtype=np.float32)
@@ -275,16 +325,13 @@ class SpeakerDiarization:
                 if kc == ci and lab >= 0:
                     act[:, lab] = np.maximum(act[:, lab], m[:, sp])
             clustered.append(act)
-        agg = aggregate(clustered, starts, len(x), self.win)          # [frames, clusters]
-        n_valid = min(agg.shape[0], int(len(x) / 270))
+        agg = aggregate(clustered, starts, n_samples, self.win)          # [frames, clusters]
+        n_valid = min(agg.shape[0], int(n_samples / 270))
         agg, count = agg[:n_valid], count[:n_valid]
         # to_diarization: at each frame the `count` most active clusters speak
         order = np.argsort(-agg, axis=1)
-        binary = np.zeros_like(agg)
-        for t in range(n_valid):
-            for r in range(min(count[t], n_clusters)):
-                if agg[t, order[t, r]] > 0:
-                    binary[t, order[t, r]] = 1.0
+        ranks = np.argsort(order, axis=1)                                  # rank of every cluster at every frame
+        binary = ((ranks < count[:, None]) & (agg > 0)).astype(np.float32)
         tracks = []
         first_seen = {}
         for c in range(n_clusters):

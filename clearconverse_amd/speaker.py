@@ -51,6 +51,20 @@ class _SpeakerNet:
         except Exception:
             pass
 
+    def _groups(self, crops: Sequence):
+        """Split a crop list into launches that respect both capacities (crop count and total samples)."""
+        i0, n = 0, len(crops)
+        while i0 < n:
+            i1, tot = i0, 0
+            while i1 < n and i1 - i0 < self.max_crops:
+                k = int(crops[i1].numel() if torch.is_tensor(crops[i1]) else np.asarray(crops[i1]).size)
+                if tot + k > 0.9 * self.max_samples and i1 > i0:
+                    break
+                tot += k
+                i1 += 1
+            yield i0, i1
+            i0 = i1
+
     def _pack(self, crops: Sequence):
         """Concatenate crops (1-D tensors/arrays, any device) into one device buffer + offset table."""
         ts = []
@@ -74,14 +88,14 @@ class XVectorEmbedder(_SpeakerNet):
         (optional): one 1-D frame-weight vector per crop (any resolution) for weighted statistics pooling."""
         out = torch.empty(len(crops), self.DIM, device=self.device, dtype=torch.float32)
         i64p, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int)
-        for i0 in range(0, len(crops), self.max_crops):
-            part = crops[i0:i0 + self.max_crops]
+        for i0, i1 in self._groups(crops):
+            part = crops[i0:i1]
             buf, offs, lens = self._pack(part)
-            o = out[i0:i0 + len(part)]
+            o = out[i0:i1]
             if weights is None:
                 wptr, woffs, wlens = None, None, None
             else:
-                wbuf, wo, wl = self._pack(weights[i0:i0 + self.max_crops])
+                wbuf, wo, wl = self._pack(weights[i0:i1])
                 wptr, woffs, wlens = wbuf.data_ptr(), wo.ctypes.data_as(i64p), wl.ctypes.data_as(ip)
             self.ctx.check(self.lib.ccx_speaker_embed(self.handle, buf.data_ptr(), offs.ctypes.data_as(i64p), lens.ctypes.data_as(ip),
                                                       len(part), wptr, woffs, wlens, o.data_ptr(), _lib.current_stream_ptr()),
@@ -107,8 +121,8 @@ class SegmentationNet(_SpeakerNet):
 
     def segment_batch(self, crops: Sequence) -> List[torch.Tensor]:
         outs: List[torch.Tensor] = []
-        for i0 in range(0, len(crops), self.max_crops):
-            part = crops[i0:i0 + self.max_crops]
+        for i0, i1 in self._groups(crops):
+            part = crops[i0:i1]
             buf, offs, lens = self._pack(part)
             cap = int(sum(lens) // 270 + 4 * len(part))
             out = torch.empty(cap, self.n_classes, device=self.device, dtype=torch.float32)

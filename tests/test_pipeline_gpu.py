@@ -69,4 +69,4 @@ def test_pinned_batch_driver_counts(models):
     assert r["embeds"] == 2 * 4 + 2 * 2 + n_win + 2 * 2 * 4
     assert len(r["records"]) == r["whisper_calls"] and all(len(x["tokens"]) <= 8 for x in r["records"])
     assert all(np.isfinite(s) for s in r["sims"])
-    assert set(bp.stage_ms) >= {"load_audio_gate", "vad", "diarization", "profiles", "separate", "whisper_overlap"}
+    assert set(bp.stage_ms) >= {"load_audio_gate", "vad", "diarization", "profiles", "separate", "whisper"}

@@ -188,3 +188,27 @@ def test_transcribe_call_surface(mini):
     assert isinstance(out["text"], str) and "segments" in out
     with pytest.raises(Exception):
         m.transcribe(audio, temperature=0.1)
+
+
+def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
+    """B > 16 switches the decode chain to the stand-alone resolve+LayerNorm kernel and multi-tile skinny
+    GEMMs; the tokens of a sequence must not depend on how many batch mates it has."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        small = dev
+        m.log_mel(small, n); m.encode(4)
+        prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
+        a = m.decode_greedy(prompts, sample_len=16)
+        big = small.repeat(10, 1).contiguous()                      # 40 sequences: the same 4 windows, 10 times
+        m.log_mel(big, n * 10); m.encode(40)
+        b = m.decode_greedy(prompts * 10, sample_len=16)
+        for i in range(40):
+            assert b[i]["tokens"] == a[i % 4]["tokens"], i
+            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-3
+    finally:
+        m.close()
