@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--workload", choices=("pipeline", "whisper"), default="pipeline")
     ap.add_argument("--batch", type=int, default=None, help="30 s clips per GPU per step (default 32 pipeline / 8 whisper)")
     ap.add_argument("--sample-len", type=int, default=224)
-    ap.add_argument("--whisper-group", type=int, default=96, help="sequences decoded together in the pipeline workload")
+    ap.add_argument("--whisper-group", type=int, default=192, help="sequences decoded together in the pipeline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="one extra (untimed) step with a sync after every stage")
     args = ap.parse_args()

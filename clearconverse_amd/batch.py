@@ -51,7 +51,7 @@ class BatchPipeline:
         for i0 in range(0, len(crops), min(self.group, w.max_batch)):
             grp = crops[i0:i0 + min(self.group, w.max_batch)]
             n = [int(c.numel()) for c in grp]
-            buf = torch.zeros(len(grp), max(n), device=w.device, dtype=torch.float32)
+            buf = torch.empty(len(grp), max(n), device=w.device, dtype=torch.float32)   # kernels read only [:n_samples]
             for j, c in enumerate(grp):
                 buf[j, :n[j]] = c
             w.log_mel(buf, n)
@@ -90,7 +90,7 @@ class BatchPipeline:
         sched = [(spk, int(s * SR), int(e * SR)) for spk, s, e in SCHEDULE_30S]
         crops = [den[b, s:e] for b in range(B) for _, s, e in sched]
         n = [int(c.numel()) for c in crops]
-        buf = torch.zeros(len(crops), max(n), device=audio.device)
+        buf = torch.empty(len(crops), max(n), device=audio.device)
         for i, c in enumerate(crops):
             buf[i, :n[i]] = c
         clean = self._peak(m["denoiser"].reduce_batch(buf, n, self.nra), n, 0.0)
@@ -135,7 +135,7 @@ class BatchPipeline:
             regions += [(b, "A" if spk == "A" else "B", s, cut), (b, "B" if spk == "A" else "A", cut, e)]
         rcrops = [den[b, s:e] for b, _, s, e in regions]
         rn = [int(c.numel()) for c in rcrops]
-        rbuf = torch.zeros(len(rcrops), max(rn), device=audio.device)
+        rbuf = torch.empty(len(rcrops), max(rn), device=audio.device)
         for i, c in enumerate(rcrops):
             rbuf[i, :rn[i]] = c
         sep = []

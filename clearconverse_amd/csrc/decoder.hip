@@ -343,6 +343,53 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
   }
 }
 
+// Stand-alone split-KV combine -> bf16 attention output [M][H*64] (used instead of the in-GEMV prologue when
+// many sequences are decoded: every weight-panel block would otherwise redo the whole combine).
+__global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                          int nsplit, bf16_t* __restrict__ out, int M, int H) {
+  const int e = blockIdx.x * 256 + threadIdx.x;   // (row, head, 8-wide d chunk)
+  if (e >= M * H * 8) return;
+  const int c = e & 7, h = (e >> 3) % H, m = e / (8 * H);
+  const float2* ml = (const float2*)(part_ml + ((long)(m * H + h) * nsplit) * 2);
+  const float* ob = part_o + ((long)(m * H + h) * nsplit) * 64 + 8 * c;
+  float2 mlv[8];
+  float4 oa[8], oc[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const int sc = s < nsplit ? s : 0;
+    mlv[s] = ml[sc];
+    oa[s] = *(const float4*)(ob + sc * 64);
+    oc[s] = *(const float4*)(ob + sc * 64 + 4);
+    if (s >= nsplit) mlv[s] = make_float2(-1e30f, 0.f);
+  }
+  float mx = -1e30f;
+#pragma unroll
+  for (int s = 0; s < 8; s++) mx = fmaxf(mx, mlv[s].x);
+  float den = 0.f, o[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; s++) {
+    const float w = (s < nsplit) ? __builtin_amdgcn_exp2f(mlv[s].x - mx) : 0.f;
+    den += w * mlv[s].y;
+    o[0] += w * oa[s].x; o[1] += w * oa[s].y; o[2] += w * oa[s].z; o[3] += w * oa[s].w;
+    o[4] += w * oc[s].x; o[5] += w * oc[s].y; o[6] += w * oc[s].z; o[7] += w * oc[s].w;
+  }
+  const float inv = 1.0f / den;
+  uint4 pk;
+  pk.x = pack_bf16x2(o[0] * inv, o[1] * inv); pk.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+  pk.z = pack_bf16x2(o[4] * inv, o[5] * inv); pk.w = pack_bf16x2(o[6] * inv, o[7] * inv);
+  *(uint4*)(out + ((long)m * H + h) * 64 + 8 * c) = pk;
+}
+
+int ccx_launch_dec_combine(ccx_ctx* ctx, const float* part_o, const float* part_ml, int nsplit, bf16_t* out, int M, int H,
+                           hipStream_t stream) {
+  CCX_REQUIRE(ctx, nsplit >= 1 && nsplit <= 8, "dec_combine: nsplit out of range");
+  hipLaunchKernelGGL(dec_combine_kernel, dim3(ccx_cdiv(M * H * 8, 256)), dim3(256), 0, stream, part_o, part_ml, nsplit, out, M, H);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
 int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
                               const float* b, bf16_t* out, float* x_out, int M, int K, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, K % 4 == 0 && K <= 1024, "dec_resolve_ln: K=%d unsupported", K);

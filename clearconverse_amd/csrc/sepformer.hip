@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256) void sep_decoder_kernel(const float* __restric
   const int u = blockIdx.y;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int T = utt_T[u], L = utt_L[u];
-  if (t >= T) return;
+  if (t >= out_stride) return;
+  if (t >= T) {  // rows past the utterance are zero (separate_batch pads / trims to T)
+    if (lane == 0) ((float2*)(out + ((long)u * out_stride + t) * 2))[0] = make_float2(0.f, 0.f);
+    return;
+  }
   float a0 = 0.f, a1 = 0.f;
   const int l_hi = t >> 3;
 #pragma unroll
@@ -580,7 +584,6 @@ int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, c
   memset(&p, 0, sizeof(p));
   p.A = s->xn; p.lda = D; p.W = s->W_fc; p.ldw = D; p.M = n_tok; p.N = 2 * D; p.K = D; p.bias = s->b_fc; p.out = s->fc; p.ldo = 2 * D;
   STRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
-  CCX_HIP(ctx, hipMemsetAsync(out, 0, (size_t)B * stride * 2 * 4, st));
   hipLaunchKernelGGL(sep_decoder_kernel, dim3(ccx_cdiv((int)stride, 4), B), dim3(256), 0, st, s->feats, s->fc, s->utt_tok0, s->utt_L,
                      s->utt_T, s->w_dec, out, (long)stride, B);
   CCX_CHECK_LAUNCH(ctx);

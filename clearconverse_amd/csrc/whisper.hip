@@ -667,7 +667,12 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     ap.q = w->dq; ap.k = L.crossK; ap.v = L.crossV; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
     ap.scale_log2e = scale_log2e; ap.part_o = w->part_o; ap.part_ml = w->part_ml;
     TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
-    TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
+    if (B > 16) {
+      TRY(ccx_launch_dec_combine(ctx, w->part_o, w->part_ml, ns, w->dattn, B, H, stream));
+      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, w->dattn));
+    } else {
+      TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
+    }
     // MLP
     TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, w->dffn, F, nullptr));
     TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, w->dffn));
