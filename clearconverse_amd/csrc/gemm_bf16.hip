@@ -27,46 +27,57 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ int keyA(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int keyB(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
 
-template <bool SWAP>
-__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, int m0, int n0,
-                                              f32x4 (&acc)[4][4]) {
+// Block geometry: WM x WN waves, each wave owns (MT*16) x 64 outputs as MT x 4 accumulators.
+//   <2,2,4>: 128x128 tile, 4 waves, 64 KB LDS (2 stages) -> 2 blocks per CU        (64 flop per LDS-DMA byte)
+//   <2,4,8>: 256x256 tile, 8 waves, 128 KB LDS (2 stages) -> 1 block per CU        (128 flop per LDS-DMA byte)
+// The encoder GEMMs (K = 768) are bound by the L2 -> LDS operand stream, not by HBM or MFMA issue, so the
+// large tile is used whenever it still yields enough tiles to fill the 256 CUs.
+template <bool SWAP, int WM, int WN, int MT>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[MT][4]) {
+  constexpr int NW = WM * WN;
+  constexpr int A_ROWS = WM * MT * 16, B_ROWS = WN * 64;
+  constexpr int A_BYTES = A_ROWS * 128, B_BYTES = B_ROWS * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = A_ROWS / 8 / NW, NB = B_ROWS / 8 / NW;   // DMA instructions (8 rows x 128 B) per wave per stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
   // ---- per-lane DMA source rows (loop invariant) ----
-  const bf16_t* srcA[4];
-  const bf16_t* srcB[4];
+  const bf16_t* srcA[NA];
+  const bf16_t* srcB[NB];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int inst = wave * 4 + i;
-    const int r = inst * 8 + (lane >> 3);
-    const int pc = lane & 7;
+  for (int i = 0; i < NA; i++) {
+    const int r = (wave * NA + i) * 8 + (lane >> 3);
     int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+    srcA[i] = p.A + (long)gm * p.lda + (((lane & 7) ^ keyA(r)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int r = (wave * NB + i) * 8 + (lane >> 3);
     int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-    srcA[i] = p.A + (long)gm * p.lda + ((pc ^ keyA(r)) << 3);
-    srcB[i] = p.W + (long)gn * p.ldw + ((pc ^ keyB(r)) << 3);
+    srcB[i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyB(r)) << 3);
   }
   auto stage = [&](int t, int buf) {
-    char* sA = smem + buf * STAGE_BYTES;
-    char* sB = sA + 16384;
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
     const int k0 = t * BK;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int inst = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sA + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sB + inst * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < NA; i++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sA + (wave * NA + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sB + (wave * NB + i) * 1024), 16, 0, 0);
   };
 
   // ---- per-lane LDS read offsets ----
   const int l15 = lane & 15, h = lane >> 4;
-  const int ka = keyA(l15);                       // rows wr*64 + mt*16 + l15
+  const int ka = keyA(l15);                       // rows wr*MT*16 + mt*16 + l15
   const int q = l15 >> 2, u = l15 & 3;
   const int kb = ((u >> 1) & 1) | (q << 1);       // rows wc*64 + 16q + 4j + u
   int offA[2], offB[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
-    offA[ks] = (wr * 64 + l15) * 128 + (((4 * ks + h) ^ ka) << 4);
+    offA[ks] = (wr * MT * 16 + l15) * 128 + (((4 * ks + h) ^ ka) << 4);
     offB[ks] = (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb) << 4);
   }
 
@@ -76,24 +87,24 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
   for (int t = 0; t < nt; t++) {
     const int buf = t & 1;
     if (t + 1 < nt) stage(t + 1, buf ^ 1);
-    const char* sA = smem + buf * STAGE_BYTES;
-    const char* sB = sA + 16384;
+    const char* sA = smem + buf * STAGE;
+    const char* sB = sA + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-      bf16x8 a[4], b[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; mt++) a[mt] = *(const bf16x8*)(sA + offA[ks] + mt * 16 * 128);
+      bf16x8 b[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) b[j] = *(const bf16x8*)(sB + offB[ks] + j * 4 * 128);
 #pragma unroll
-      for (int mt = 0; mt < 4; mt++)
+      for (int mt = 0; mt < MT; mt++) {
+        const bf16x8 a = *(const bf16x8*)(sA + offA[ks] + mt * 16 * 128);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           if (SWAP)
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[mt], acc[mt][j], 0, 0, 0);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[mt][j], 0, 0, 0);
           else
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], acc[mt][j], 0, 0, 0);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[mt][j], 0, 0, 0);
         }
+      }
     }
     __syncthreads();
   }
@@ -106,32 +117,33 @@ __device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& vali
   return (long)g * p.rpb_out + i + p.roff;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
+template <int EPI, int WM, int WN, int MT>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4 * (MT == 4 ? 2 : 1)) void gemm_bf16_nt_kernel(GemmParams p) {
+  constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + TBN - 1) / TBN;
   // XCD-aware bijective remap (blocks b, b+8 share an XCD/L2): give each XCD a contiguous
   // run of tiles so the A row-panel and the (small) W are re-read from that XCD's L2.
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
   const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
   const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TBM, n0 = tn * TBN;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int l15 = lane & 15, h = lane >> 4;
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MT; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (EPI == EPI_HEADS) {
     const int blk = n0 / p.d_model + p.first_block;  // 0=q 1=k 2=v  (d_model % 128 == 0)
     if (blk == 2 && p.v_transposed) {
-      gemm_mainloop<false>(p, smem, m0, n0, acc);
+      gemm_mainloop<false, WM, WN, MT>(p, smem, m0, n0, acc);
       // lane: column n = n0 + wc*64 + 16q + 4j + u ; rows m0 + wr*64 + mt*16 + 4h + reg
       const int q = l15 >> 2, u = l15 & 3;
 #pragma unroll
@@ -140,8 +152,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
         const int nn = n % p.d_model, hh = nn >> 6, d = nn & 63;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-          const int m = m0 + wr * 64 + mt * 16 + 4 * h;
+        for (int mt = 0; mt < MT; mt++) {
+          const int m = m0 + wr * MT * 16 + mt * 16 + 4 * h;
           if (m < p.M) {
             const int b = m / p.S, s = m - b * p.S;
             bf16_t* dst = p.hv + ((long)(b * p.n_head + hh) * 64 + d) * p.Spad + s;
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
     }
   }
 
-  gemm_mainloop<true>(p, smem, m0, n0, acc);
+  gemm_mainloop<true, WM, WN, MT>(p, smem, m0, n0, acc);
 
   // lane: row m = m0 + wr*64 + mt*16 + l15 ; columns nb .. nb+15, value index 4j+reg
   const int nb = n0 + wc * 64 + 16 * h;
@@ -169,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
   }
 
 #pragma unroll
-  for (int mt = 0; mt < 4; mt++) {
-    const int m = m0 + wr * 64 + mt * 16 + l15;
+  for (int mt = 0; mt < MT; mt++) {
+    const int m = m0 + wr * MT * 16 + mt * 16 + l15;
     if (m >= p.M) continue;
     float v[16];
 #pragma unroll
@@ -253,13 +265,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmParams p) {
   }
 }
 
-template <int EPI>
-static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
-  const int tiles = ccx_cdiv(p.M, BM) * ccx_cdiv(p.N, BN);
+template <int EPI, int WM, int WN, int MT>
+static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+  constexpr int TBM = WM * MT * 16, TBN = WN * 64;
+  constexpr int LDS = 2 * (TBM + TBN) * 128;
+  const int tiles = ccx_cdiv(p.M, TBM) * ccx_cdiv(p.N, TBN);
   static bool attr_set = false;
   if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI, WM, WN, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   {
@@ -267,10 +280,25 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
     const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;  // output element size
     ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * p.K,
                       2.0 * ((double)p.M * p.K + (double)p.N * p.K) + obytes * p.M * (double)p.N);
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel<EPI>, dim3(tiles), dim3(256), 2 * STAGE_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, WM, WN, MT>), dim3(tiles), dim3(WM * WN * 64), LDS, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
+}
+
+template <int EPI>
+static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+  // 256x256 tiles once there are enough of them to fill the 256 CUs and N is wide enough not to waste half a tile;
+  // the 128x128 kernel (2 blocks per CU) otherwise.  CCX_GEMM_TILE=128|256 forces one for A/B measurements.
+  static const int forced = [] { const char* e = getenv("CCX_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const long big_tiles = (long)ccx_cdiv(p.M, 256) * ccx_cdiv(p.N, 256);
+  // stores are not guarded along N: the destination must cover N rounded up to the tile width
+  bool fits = p.N >= 256 && (p.N % 256 == 0 || p.N >= 1024);
+  if (EPI == EPI_HEADS) fits = fits && p.N % 256 == 0 && p.d_model % 256 == 0;
+  else fits = fits && p.ldo >= (long)ccx_cdiv(p.N, 256) * 256;
+  const bool big = fits && (forced == 256 || (forced != 128 && big_tiles >= 224));
+  if (big) return launch_epi_geo<EPI, 2, 4, 8>(ctx, p, stream);
+  return launch_epi_geo<EPI, 2, 2, 4>(ctx, p, stream);
 }
 
 int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stream) {
