@@ -177,10 +177,7 @@ class VoiceActivityDetection:
             starts, cr = self._chunks(x)
             plans.append((starts, len(crops), len(cr)))
             crops += cr
-        outs = []
-        for i in range(0, len(crops), self.batch_size):
-            outs += self.net.segment_batch(crops[i:i + self.batch_size])
-        outs = [o.cpu().numpy() for o in outs]
+        outs = self.net.segment_numpy(crops) if crops else []
         anns = []
         for x, pl in zip(xs, plans):
             if pl is None:
@@ -267,10 +264,7 @@ class SpeakerDiarization:
                 cr.append(c)
             plans.append((starts, len(crops), len(cr)))
             crops += cr
-        seg = []
-        for i in range(0, len(crops), self.batch_size):
-            seg += self.net.segment_batch(crops[i:i + self.batch_size])
-        seg = [o.cpu().numpy() for o in seg]
+        seg = self.net.segment_numpy(crops) if crops else []
         # local speakers of every window of every item
         per_item = []
         e_crops, e_weights = [], []
@@ -293,10 +287,7 @@ class SpeakerDiarization:
                     e_crops.append(crops[i0 + ci])
                     e_weights.append(torch.from_numpy(w.astype(np.float32)))
             per_item.append((starts, multi, keys))
-        embs = []
-        for i in range(0, len(e_crops), self.batch_size):
-            embs.append(self.emb.embed_batch(e_crops[i:i + self.batch_size], weights=e_weights[i:i + self.batch_size]).cpu().numpy())
-        embs = np.concatenate(embs, axis=0) if embs else np.zeros((0, 512), dtype=np.float32)
+        embs = self.emb.embed_batch(e_crops, weights=e_weights).cpu().numpy() if e_crops else np.zeros((0, 512), dtype=np.float32)
         anns, e0 = [], 0
         for x, it in zip(xs, per_item):
             if it is None or not it[2]:

@@ -66,14 +66,16 @@ class _SpeakerNet:
             i0 = i1
 
     def _pack(self, crops: Sequence):
-        """Concatenate crops (1-D tensors/arrays, any device) into one device buffer + offset table."""
-        ts = []
-        for c in crops:
-            t = c if torch.is_tensor(c) else torch.from_numpy(np.asarray(c, dtype=np.float32))
-            ts.append(t.reshape(-1).to(self.device, torch.float32))
+        """Concatenate crops (1-D tensors/arrays, any device) into one device buffer + offset table.
+        Host-resident crops are concatenated on the host first (ONE upload instead of one per crop)."""
+        ts = [c.reshape(-1) if torch.is_tensor(c) else torch.from_numpy(np.asarray(c, dtype=np.float32)).reshape(-1) for c in crops]
         lens = [int(t.numel()) for t in ts]
         offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-        buf = torch.cat(ts) if len(ts) > 1 else ts[0].contiguous()
+        if all(not t.is_cuda for t in ts):
+            buf = (torch.cat(ts) if len(ts) > 1 else ts[0]).to(torch.float32).to(self.device)
+        else:
+            ts = [t.to(self.device, torch.float32) for t in ts]
+            buf = torch.cat(ts) if len(ts) > 1 else ts[0].contiguous()
         return buf, offs, np.asarray(lens, dtype=np.int32)
 
 
@@ -118,6 +120,26 @@ class SegmentationNet(_SpeakerNet):
         super().__init__(1, state_dict, n_classes, powerset, max_crops, max_samples, device, ctx)
         self.n_classes = n_classes
         self.powerset = bool(powerset)
+
+    def segment_numpy(self, crops: Sequence) -> List[np.ndarray]:
+        """Like segment_batch but returns host arrays with ONE device->host copy per launch group."""
+        res: List[np.ndarray] = []
+        i64p, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int)
+        for i0, i1 in self._groups(crops):
+            part = crops[i0:i1]
+            buf, offs, lens = self._pack(part)
+            cap = int(sum(lens) // 270 + 4 * len(part))
+            out = torch.empty(cap, self.n_classes, device=self.device, dtype=torch.float32)
+            frames = np.zeros(len(part), dtype=np.int32)
+            self.ctx.check(self.lib.ccx_speaker_segment(self.handle, buf.data_ptr(), offs.ctypes.data_as(i64p), lens.ctypes.data_as(ip),
+                                                        len(part), out.data_ptr(), cap, frames.ctypes.data_as(ip), _lib.current_stream_ptr()),
+                           "ccx_speaker_segment")
+            host = out[: int(frames.sum())].cpu().numpy()
+            r = 0
+            for f in frames:
+                res.append(host[r:r + int(f)])
+                r += int(f)
+        return res
 
     def segment_batch(self, crops: Sequence) -> List[torch.Tensor]:
         outs: List[torch.Tensor] = []
