@@ -597,7 +597,7 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
   dim3 grid(B * p.H, nsplit);
   {
     const double keys = p.pos ? 0.0 : (double)p.T;  // self-attention length varies per row: not priced
-    ccx_prof_scope ps(ctx, stream, final_out ? "dec_attention_self" : "dec_attention_cross", 4.0 * B * p.H * keys * 64,
+    ccx_prof_scope ps(ctx, stream, final_out ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
                       (double)B * p.H * keys * 64 * 2 * 2);
     if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), 0, stream, p);
