@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(
     const float* __restrict__ dft_sin,  // [400][208]
     const float* __restrict__ mel_fb,   // [80][208]
     const int* __restrict__ mel_range,  // [80][2]  first bin, one-past-last bin
-    float* __restrict__ raw,            // [B][80][Fraw]
+    float* __restrict__ raw,            // [B][80][Fraw]  (only frames < gridDim.x*32 are written)
     unsigned int* __restrict__ gmax_bits, int Fraw) {
   __shared__ __attribute__((aligned(16))) float xs[LM_SPAN];
   __shared__ __attribute__((aligned(16))) float pw[LM_FRAMES * LM_PSTRIDE];
@@ -106,7 +106,7 @@ __global__ void logmel_init_max_kernel(unsigned int* gmax_bits, int B) {
 // One block = 64 frames of one clip.
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(
     const float* __restrict__ raw, const unsigned int* __restrict__ gmax_bits, const int* __restrict__ n_samples,
-    const int* __restrict__ seek, const int* __restrict__ seg_len, int Fraw,
+    const int* __restrict__ seek, const int* __restrict__ seg_len, int Fraw, int Fcomp,
     float* __restrict__ mel_out,   // [B][80][3000] or nullptr
     bf16_t* __restrict__ im2col) { // [B*3000][256] or nullptr
   __shared__ float tile[80][67];   // frames t0-1 .. t0+64 (66 used)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(
     if (t >= 0 && t < valid) {
       const int fr = s0 + t;
       float r = -10.f;  // frames past the computed range are pure zero padding: log10(1e-10)
-      if (fr < Fraw && fr < total_frames) r = raw[((long)b * 80 + c) * Fraw + fr];
+      if (fr < Fcomp && fr < total_frames) r = raw[((long)b * 80 + c) * Fraw + fr];
       // frames beyond the (padded) signal do not exist in the reference; pad_or_trim pads with 0
       v = (fr < total_frames) ? (fmaxf(r, floorv) + 4.0f) * 0.25f : 0.f;
     }
@@ -155,16 +155,17 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(
 }
 
 int ccx_launch_logmel(ccx_ctx* ctx, const LogmelTables& tb, const float* audio, long audio_stride,
-                      const int* n_samples_dev, const int* seek_dev, const int* seg_len_dev, int B, int Fraw, float* raw,
+                      const int* n_samples_dev, const int* seek_dev, const int* seg_len_dev, int B, int Fraw, int Fcomp, float* raw,
                       unsigned int* gmax_bits, float* mel_out, bf16_t* im2col, hipStream_t stream) {
-  CCX_REQUIRE(ctx, B > 0 && Fraw > 0 && Fraw % LM_FRAMES == 0, "logmel: bad B=%d / Fraw=%d", B, Fraw);
+  CCX_REQUIRE(ctx, B > 0 && Fraw > 0 && Fraw % LM_FRAMES == 0 && Fcomp > 0 && Fcomp <= Fraw && Fcomp % LM_FRAMES == 0,
+              "logmel: bad B=%d / Fraw=%d / Fcomp=%d", B, Fraw, Fcomp);
   hipLaunchKernelGGL(logmel_init_max_kernel, dim3(ccx_cdiv(B, 64)), dim3(64), 0, stream, gmax_bits, B);
   CCX_CHECK_LAUNCH(ctx);
-  hipLaunchKernelGGL(logmel_power_kernel, dim3(Fraw / LM_FRAMES, B), dim3(256), 0, stream, audio, audio_stride,
+  hipLaunchKernelGGL(logmel_power_kernel, dim3(Fcomp / LM_FRAMES, B), dim3(256), 0, stream, audio, audio_stride,
                      n_samples_dev, tb.dft_cos, tb.dft_sin, tb.mel_fb, tb.mel_range, raw, gmax_bits, Fraw);
   CCX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(logmel_finalize_kernel, dim3(ccx_cdiv(3000, 64), B), dim3(256), 0, stream, raw, gmax_bits,
-                     n_samples_dev, seek_dev, seg_len_dev, Fraw, mel_out, im2col);
+                     n_samples_dev, seek_dev, seg_len_dev, Fraw, Fcomp, mel_out, im2col);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }

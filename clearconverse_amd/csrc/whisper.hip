@@ -310,6 +310,16 @@ int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, i
   return CCX_OK;
 }
 
+int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, !w->finalized, "whisper: set_max_audio after finalize");
+  CCX_REQUIRE(w->ctx, seconds >= 1.0 && seconds <= 7200.0, "whisper: max audio %.1f s out of range [1, 7200]", seconds);
+  const long frames = (long)(seconds * 100.0) + 8;
+  w->Fraw = (int)((frames + 31) / 32 * 32);
+  if (w->Fraw < 3008) w->Fraw = 3008;
+  return CCX_OK;
+}
+
 int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* r) {
   if (!w) return CCX_ERR_ARG;
   CCX_REQUIRE(w->ctx, r, "whisper: rules null");
@@ -487,12 +497,14 @@ int ccx_whisper_logmel(ccx_whisper* w, const float* audio, int64_t stride, const
   hipStream_t stream = (hipStream_t)stream_;
   CCX_REQUIRE(w->ctx, w->finalized, "whisper: not finalized");
   CCX_REQUIRE(w->ctx, audio && n_samples && B >= 1 && B <= w->max_batch, "whisper_logmel: bad arguments (B=%d, max %d)", B, w->max_batch);
+  long fcomp = 32;
   for (int b = 0; b < B; b++) {
     CCX_REQUIRE(w->ctx, n_samples[b] >= 0 && n_samples[b] <= stride, "whisper_logmel: n_samples[%d]=%d exceeds stride", b, n_samples[b]);
     const int s = seek ? seek[b] : 0;
     // frames that touch audio content must lie inside the computed range
     const long need_frames = ((long)n_samples[b] + 200 + 159) / 160 + 1;
-    CCX_REQUIRE(w->ctx, need_frames <= w->Fraw, "whisper_logmel: clip %d (%d samples) is longer than one 30 s window; split it on the host", b, n_samples[b]);
+    CCX_REQUIRE(w->ctx, need_frames <= w->Fraw, "whisper_logmel: clip %d (%d samples) exceeds the configured maximum of %d frames (ccx_whisper_set_max_audio)", b, n_samples[b], w->Fraw);
+    if (need_frames > fcomp) fcomp = need_frames;
     CCX_REQUIRE(w->ctx, s >= 0, "whisper_logmel: negative seek");
   }
   // segment_size = min(N_FRAMES, content_frames - seek), content_frames = n_samples // 160 (transcribe.py)
@@ -506,7 +518,8 @@ int ccx_whisper_logmel(ccx_whisper* w, const float* audio, int64_t stride, const
   CCX_HIP(w->ctx, hipMemcpyAsync(w->lm_seek, sk.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->lm_seg, seg.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host staging vectors go out of scope
-  return ccx_launch_logmel(w->ctx, w->lm, audio, stride, w->lm_n, w->lm_seek, w->lm_seg, B, w->Fraw, w->lm_raw,
+  fcomp = (fcomp + 31) / 32 * 32;   // only frames that touch audio are computed; everything later is log10(1e-10)
+  return ccx_launch_logmel(w->ctx, w->lm, audio, stride, w->lm_n, w->lm_seek, w->lm_seg, B, w->Fraw, (int)fcomp, w->lm_raw,
                            w->lm_max, mel_out, w->im2col, stream);
 }
 

@@ -21,7 +21,7 @@ from .weights import (SepDims, WhisperDims, find_whisper_checkpoint, synthetic_p
 from .whisper import WhisperModel
 
 
-def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None,
+def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256) -> Dict[str, object]:
     if not torch.cuda.is_available():
@@ -35,7 +35,7 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     else:
         wd = whisper_dims or WhisperDims.small_en()
         wsd = synthetic_whisper_state_dict(wd, seed=seed)
-    whisper = WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx)
+    whisper = WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds)
     sd_ = sep_dims or SepDims()
     separator = SepformerSeparator(sd_, synthetic_sepformer_state_dict(sd_, seed=seed + 1), max_tokens=sep_tokens, max_utts=64,
                                    device=dev_index, ctx=ctx)

@@ -33,7 +33,7 @@ INPUT_STRIDE = 2       # mel frames per encoder position
 class WhisperModel:
     def __init__(self, dims: WhisperDims, state_dict: Dict[str, torch.Tensor], max_batch: int = 8,
                  device: int = 0, rules: Optional[DecodeRules] = None, tokenizer=None,
-                 ctx: Optional[_lib.Context] = None):
+                 ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0):
         if not torch.cuda.is_available():
             raise _lib.CcxError("WhisperModel needs a ROCm GPU: the HIP path has no CPU fallback")
         self.dims = dims
@@ -48,6 +48,8 @@ class WhisperModel:
         self.ctx.check(self.lib.ccx_whisper_create(self.ctx.handle, C.byref(cd), self.max_batch, C.byref(h)),
                        "ccx_whisper_create")
         self.handle = h
+        self.max_audio_seconds = float(max_audio_seconds)
+        self.ctx.check(self.lib.ccx_whisper_set_max_audio(self.handle, self.max_audio_seconds), "ccx_whisper_set_max_audio")
         self._load(state_dict)
         self.set_rules(self.rules)
 
@@ -183,8 +185,8 @@ class WhisperModel:
             state.append(dict(seek=0, all_tokens=list(ipt), n_init=len(ipt), reset=0, segments=[],
                               content=len(clips[i]) // HOP))
         stride = max(max((len(c) for c in clips), default=1), 1)
-        if stride > N_SAMPLES:
-            raise _lib.CcxError("clips longer than 30 s must be split by the caller (one 30 s log-mel window per call)")
+        if stride > self.max_audio_seconds * SAMPLE_RATE:
+            raise _lib.CcxError(f"clip of {stride / SAMPLE_RATE:.1f} s exceeds max_audio_seconds={self.max_audio_seconds}")
         # clips stay resident on the GPU for all windows
         host = np.zeros((n, stride), dtype=np.float32)
         for i, c in enumerate(clips):

@@ -89,6 +89,9 @@ void ccx_whisper_destroy(ccx_whisper* w);
  * or a device pointer.  Unknown names are an error. */
 int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, int dtype, int ndim,
                            const int64_t* shape);
+/* Longest clip (seconds) ccx_whisper_logmel must accept (default 30); call before finalize.  The log-mel of the
+ * whole clip is normalised with its global maximum, exactly like whisper.audio.log_mel_spectrogram. */
+int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds);
 /* Checks every tensor is present, builds the fused/bf16 device layouts, uploads. */
 int ccx_whisper_finalize(ccx_whisper* w);
 int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* rules);

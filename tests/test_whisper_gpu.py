@@ -212,3 +212,28 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
             assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-3
     finally:
         m.close()
+
+
+def test_long_audio_multi_window_logmel_and_transcribe(ccx_ctx):
+    """Audio longer than 30 s: the log-mel is normalised over the WHOLE clip and transcribe() walks 30 s
+    windows with `seek` (transcribe.py main loop)."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=2, ctx=ccx_ctx, max_audio_seconds=80.0)
+    try:
+        clip = np.concatenate([synthetic_clip(0, 30.0), 0.3 * synthetic_clip(1, 30.0), synthetic_clip(2, 30.0)[: 16000 * 11]])
+        dev = torch.from_numpy(clip[None]).cuda()
+        full = R.log_mel_spectrogram(torch.from_numpy(clip))
+        content = len(clip) // 160
+        for seek in (0, 3000, 6500):
+            mel = m.log_mel(dev, [len(clip)], seek=[seek], return_mel=True).cpu()[0]
+            ref = R.pad_or_trim(full[:, seek: seek + min(3000, content - seek)], 3000)
+            assert float((mel - ref).abs().max()) < 2e-3, seek
+        out = m.transcribe(clip, initial_prompt="This is a conversation between two people.")
+        seeks = [s["seek"] for s in out["segments"]]
+        assert len(set(seeks)) >= 3 and seeks == sorted(seeks)          # at least three 30 s windows were decoded, in order
+        with pytest.raises(Exception):
+            m.transcribe(np.zeros(16000 * 90, dtype=np.float32))          # beyond max_audio_seconds: loud failure
+    finally:
+        m.close()
