@@ -7,6 +7,7 @@
 // model.py / decoding.py [UPSTREAM-RECALL -- not vendored in the reference]; the CPU restatement
 // the tests compare against is oracle/whisper_ref.py.
 #include <map>
+#include <chrono>
 #include <math.h>
 #include "../../include/ccx.h"
 #include "attention.h"
@@ -105,9 +106,20 @@ struct ccx_whisper {
   int max_prompt_cap = 0, sample_cap = 0;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
   // stream (stream capture is illegal there)
-  std::map<int, hipGraphExec_t> graphs;
+  std::map<long, hipGraphExec_t> graphs;
   hipStream_t own_stream = nullptr;
   hipEvent_t own_event = nullptr;
+  // decode lanes: disjoint row ranges of one batch stepping concurrently on their own streams, staggered so
+  // that one lane's HBM-bound cross attention overlaps the other lanes' latency-bound linears.  The gain is
+  // modest (4 % at 192 sequences): the small kernels slow down 3-5x while HBM is saturated by another lane.
+  static constexpr int kMaxLanes = 4;
+  static constexpr int kLanePool = 8;
+  hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
+                                             // queue run strictly one after the other, so lanes are picked by a probe
+  std::map<hipStream_t, std::vector<hipStream_t>> lane_sets;   // lane-0 stream -> streams that overlap with it and each other
+  int* probe_sink = nullptr;
+  hipEvent_t lane_start[kMaxLanes] = {}, lane_poll[2][kMaxLanes] = {};
+  int* poll_host = nullptr;                  // pinned [2][kMaxLanes]
 };
 
 namespace {
@@ -279,6 +291,14 @@ void ccx_whisper_destroy(ccx_whisper* w) {
   for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
   if (w->own_stream) hipStreamDestroy(w->own_stream);
   if (w->own_event) hipEventDestroy(w->own_event);
+  for (int i = 0; i < ccx_whisper::kMaxLanes; i++) {
+    if (w->lane_start[i]) hipEventDestroy(w->lane_start[i]);
+    if (w->lane_poll[0][i]) hipEventDestroy(w->lane_poll[0][i]);
+    if (w->lane_poll[1][i]) hipEventDestroy(w->lane_poll[1][i]);
+  }
+  for (int i = 0; i < ccx_whisper::kLanePool; i++)
+    if (w->lane_pool[i]) hipStreamDestroy(w->lane_pool[i]);
+  if (w->poll_host) hipHostFree(w->poll_host);
   for (void* p : w->allocs) hipFree(p);
   delete w;
 }
@@ -487,6 +507,14 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   TRY(dev_alloc(w, &w->gen, (size_t)B * w->sample_cap, true));
   CCX_HIP(w->ctx, hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
   CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->own_event, hipEventDisableTiming));
+  for (int i = 0; i < ccx_whisper::kMaxLanes; i++) {
+    CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_start[i], hipEventDisableTiming));
+    CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_poll[0][i], hipEventDisableTiming));
+    CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_poll[1][i], hipEventDisableTiming));
+  }
+  for (int i = 0; i < ccx_whisper::kLanePool; i++) CCX_HIP(w->ctx, hipStreamCreateWithFlags(&w->lane_pool[i], hipStreamNonBlocking));
+  TRY(dev_alloc(w, &w->probe_sink, (size_t)64, true));
+  CCX_HIP(w->ctx, hipHostMalloc((void**)&w->poll_host, 2 * ccx_whisper::kMaxLanes * sizeof(int), 0));
   w->finalized = true;
   return CCX_OK;
 }
@@ -606,26 +634,89 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// ---- lane stream selection ----
+// HIP multiplexes streams onto a handful of hardware queues, and streams that share a queue execute strictly one
+// after the other (tools/microbench_lanes2.hip: some pairs of 8 fresh streams take 2x, the others 1x).  The mapping
+// is fixed when a stream is created but not queryable, so it is measured: a few ~50 us spin kernels per stream.
+__global__ void lane_probe_spin(int* sink, long cycles) {
+  const long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < cycles) {}
+  if (sink && threadIdx.x == 0) atomicAdd(sink, 1);
+}
+
+double lane_probe_time(ccx_whisper* w, hipStream_t a, hipStream_t b) {
+  hipStreamSynchronize(a);
+  if (b) hipStreamSynchronize(b);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < 4; k++) {
+    hipLaunchKernelGGL(lane_probe_spin, dim3(1), dim3(64), 0, a, w->probe_sink, 120000L);
+    if (b) hipLaunchKernelGGL(lane_probe_spin, dim3(1), dim3(64), 0, b, w->probe_sink + 1, 120000L);
+  }
+  hipStreamSynchronize(a);
+  if (b) hipStreamSynchronize(b);
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// streams (up to `want`) that run concurrently with s0 and with each other; fewer if the probe finds fewer
+const std::vector<hipStream_t>& lane_streams_for(ccx_whisper* w, hipStream_t s0, int want) {
+  auto it = w->lane_sets.find(s0);
+  if (it != w->lane_sets.end()) return it->second;   // probed once per lane-0 stream (always for the maximum)
+  (void)want;
+  std::vector<hipStream_t>& set = w->lane_sets[s0];
+  set.clear();
+  lane_probe_time(w, s0, nullptr);                        // warm-up (code object load)
+  double single = lane_probe_time(w, s0, nullptr);
+  const double s2 = lane_probe_time(w, s0, nullptr);
+  if (s2 < single) single = s2;
+  for (int c = 0; c < ccx_whisper::kLanePool && (int)set.size() < ccx_whisper::kMaxLanes - 1; c++) {
+    hipStream_t cand = w->lane_pool[c];
+    bool ok = lane_probe_time(w, s0, cand) < 1.5 * single;
+    for (size_t j = 0; ok && j < set.size(); j++) ok = lane_probe_time(w, set[j], cand) < 1.5 * single;
+    if (ok) set.push_back(cand);
+  }
+  if (getenv("CCX_DEBUG_LANES")) fprintf(stderr, "[lanes] probe: single %.0f us, %zu concurrent streams found\n", single, set.size());
+  return set;
+}
+
 int cross_split(int B, int H) {
   // enough blocks to fill the chip, and <= 256 keys per block (one 64-key chunk per wave)
   int ns = ccx_cdiv(512, B * H);
   if (ns < 6) ns = 6;
+  if (B > 16) {
+    // many sequences: CCX_CROSS_SPLIT=n overrides (1 = whole key range per block, no partials / combine)
+    const char* e = getenv("CCX_CROSS_SPLIT");
+    const int forced = e ? atoi(e) : 0;
+    if (forced >= 1) ns = forced;
+  }
   if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
   return ns;
 }
 
-// One decoder step for B sequences on `stream`.  logits go to `logits` with row stride ld.
-// The residual stream ping-pongs between dx and dx2: out-proj / cross-out / FFN2 only write split-K
-// partial slabs (w->pend) and the next LayerNorm prologue folds them in (decoder.hip).
-int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, hipStream_t stream) {
+// One decoder step for the B sequences [b0, b0 + B) on `stream` (a "lane": every per-sequence buffer is
+// addressed through its row offset, so disjoint lanes can step concurrently on different streams).
+// logits go to `logits` (row 0 = sequence b0) with row stride ld.  The residual stream ping-pongs between
+// dx and dx2: out-proj / cross-out / FFN2 only write split-K partial slabs (pend) and the next LayerNorm
+// folds them in (decoder.hip).  `stagger`, if set, is recorded right before layer 0's cross attention.
+int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, int* n_done,
+             hipStream_t stream, hipEvent_t stagger = nullptr) {
   ccx_ctx* ctx = w->ctx;
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
   const float scale_log2e = 0.125f * 1.4426950408889634f;
   const int ns = cross_split(B, H);
   const long pstride = (long)B * D;
-  float* cur = w->dx;     // stream (minus the pending partials); the step's embedding is in dx
-  float* other = w->dx2;
+  const long ro = b0;
+  float* cur = w->dx + ro * D;     // stream (minus the pending partials); the step's embedding is in dx
+  float* other = w->dx2 + ro * D;
+  float* pend = w->pend + 4 * ro * D;
+  float* dq = w->dq + ro * D;
+  bf16_t* dxn = w->dxn + ro * D;
+  bf16_t* dattn = w->dattn + ro * D;
+  bf16_t* dffn = w->dffn + ro * F;
+  float* part_o = w->part_o + ro * H * ccx_whisper::kCrossSplitMax * 64;
+  float* part_ml = w->part_ml + ro * H * ccx_whisper::kCrossSplitMax * 2;
+  int* pos = w->pos + b0;
+  const long cross_off = ro * H * w->Spad * 64, self_off = ro * H * Tc * 64;
   int pend_n = 0;
   auto ln_linear = [&](int epi, const bf16_t* W, const float* bias, int N, const float* g, const float* bta, void* out, long ldo,
                        DecLinearParams* extra) -> int {
@@ -635,12 +726,12 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     int rc;
     if (B > 16) {
       // many sequences: normalise ONCE in a stand-alone kernel instead of redundantly in every weight-panel block
-      rc = ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, g, bta, w->dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
+      rc = ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, g, bta, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
       if (rc) return rc;
-      lp.act = w->dxn; lp.lda = D;
+      lp.act = dxn; lp.lda = D;
       rc = ccx_launch_dec_linear(ctx, ACT_BF16, epi, lp, stream);
     } else {
-      lp.x = cur; lp.pend = w->pend; lp.pend_n = pend_n; lp.pend_stride = pstride; lp.x_out = pend_n > 0 ? other : nullptr;
+      lp.x = cur; lp.pend = pend; lp.pend_n = pend_n; lp.pend_stride = pstride; lp.x_out = pend_n > 0 ? other : nullptr;
       lp.ln_g = g; lp.ln_b = bta; lp.eps = 1e-5f;
       rc = ccx_launch_dec_linear(ctx, ACT_LN, epi, lp, stream);
     }
@@ -652,8 +743,8 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = D; lp.K = K; lp.W = W; lp.ldw = K; lp.bias = bias; lp.act = a; lp.lda = K;
-    lp.part_o = w->part_o; lp.part_ml = w->part_ml; lp.nsplit = ns;
-    lp.out = w->pend; lp.ldo = D; lp.pend_stride = pstride;
+    lp.part_o = part_o; lp.part_ml = part_ml; lp.nsplit = ns;
+    lp.out = pend; lp.ldo = D; lp.pend_stride = pstride;
     int rc = ccx_launch_dec_linear(ctx, act, DEPI_PARTIAL, lp, stream);
     if (rc) return rc;
     pend_n = ccx_dec_linear_ksplit(K, DEPI_PARTIAL);
@@ -665,49 +756,51 @@ int dec_step(ccx_whisper* w, int B, float* logits, long ld, bool select, int sam
     {
       DecLinearParams ex;
       memset(&ex, 0, sizeof(ex));
-      ex.cache_k = L.selfK; ex.cache_v = L.selfV; ex.cache_T = Tc; ex.pos = w->pos;
-      TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, w->dq, D, &ex));
+      ex.cache_k = L.selfK + self_off; ex.cache_v = L.selfV + self_off; ex.cache_T = Tc; ex.pos = pos;
+      TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, dq, D, &ex));
     }
     DecAttnParams ap;
     memset(&ap, 0, sizeof(ap));
-    ap.q = w->dq; ap.k = L.selfK; ap.v = L.selfV; ap.H = H; ap.kv_T = Tc; ap.pos = w->pos; ap.scale_log2e = scale_log2e;
-    ap.out_bf16 = w->dattn;
+    ap.q = dq; ap.k = L.selfK + self_off; ap.v = L.selfV + self_off; ap.H = H; ap.kv_T = Tc; ap.pos = pos; ap.scale_log2e = scale_log2e;
+    ap.out_bf16 = dattn;
     TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
-    TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, w->dattn));
+    TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
     // cross attention
-    TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, w->dq, D, nullptr));
+    TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
+    if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     memset(&ap, 0, sizeof(ap));
-    ap.q = w->dq; ap.k = L.crossK; ap.v = L.crossV; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
-    ap.scale_log2e = scale_log2e; ap.part_o = w->part_o; ap.part_ml = w->part_ml;
-    TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
+    ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
+    ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
     if (B > 16) {
-      TRY(ccx_launch_dec_combine(ctx, w->part_o, w->part_ml, ns, w->dattn, B, H, stream));
-      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, w->dattn));
+      TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
+      if (ns > 1) TRY(ccx_launch_dec_combine(ctx, part_o, part_ml, ns, dattn, B, H, stream));
+      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
     } else {
+      TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
       TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     }
     // MLP
-    TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, w->dffn, F, nullptr));
-    TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, w->dffn));
+    TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, dffn, F, nullptr));
+    TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, dffn));
   }
   // resolve the last partials + final LN, then logits against the tied embedding
-  TRY(ccx_launch_dec_resolve_ln(ctx, cur, w->pend, pend_n, pstride, w->lnd_g, w->lnd_b, w->dxn, nullptr, B, D, 1e-5f, stream));
+  TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, w->lnd_g, w->lnd_b, dxn, nullptr, B, D, 1e-5f, stream));
   {
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = d.n_vocab; lp.K = D; lp.W = w->tok_emb_bf16; lp.ldw = D; lp.bias = nullptr;
-    lp.act = w->dxn; lp.lda = D; lp.out = logits; lp.ldo = ld;
+    lp.act = dxn; lp.lda = D; lp.out = logits; lp.ldo = ld;
     TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32, lp, stream));
   }
   if (select) {
     DecSelectParams sp;
     memset(&sp, 0, sizeof(sp));
-    sp.logits = logits; sp.ld_logits = ld; sp.n_vocab = d.n_vocab; sp.state = w->state; sp.prompt = w->prompt;
-    sp.max_prompt = max_prompt; sp.cur_tok = w->cur_tok; sp.pos = w->pos; sp.gen = w->gen; sp.sample_len = sample_len;
-    sp.n_done = w->n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
+    sp.logits = logits; sp.ld_logits = ld; sp.n_vocab = d.n_vocab; sp.state = w->state + b0; sp.prompt = w->prompt + ro * max_prompt;
+    sp.max_prompt = max_prompt; sp.cur_tok = w->cur_tok + b0; sp.pos = pos; sp.gen = w->gen + ro * sample_len; sp.sample_len = sample_len;
+    sp.n_done = n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
     sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
     sp.max_initial_ts = w->rules.max_initial_timestamp_index;
-    sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx; sp.D = D;
+    sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx + ro * D; sp.D = D;
     TRY(ccx_launch_dec_select(ctx, sp, B, stream));
   }
   return CCX_OK;
@@ -752,7 +845,7 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
   const long V = w->d.n_vocab;
   for (int t = 0; t < T; t++) {
     // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it
-    TRY(dec_step(w, B, logits_dev + (long)t * V, (long)T * V, t + 1 < T, 1, T, stream));
+    TRY(dec_step(w, 0, B, logits_dev + (long)t * V, (long)T * V, t + 1 < T, 1, T, w->n_done, stream));
   }
   return CCX_OK;
 }
@@ -786,40 +879,116 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
   const int total_steps = max_pl - 1 + sample_len;
   const bool use_graph = getenv("CCX_NO_GRAPH") == nullptr;
   const long ld = w->Vpad;
-  // graphs are specific to (B, sample_len, max_prompt): key on all three
-  const int key = B * 1000003 + sample_len * 1009 + max_prompt;
-  int step = 0;
-  // first step runs eagerly (also performs one-time kernel attribute setup outside of capture)
-  TRY(dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream));
-  step = 1;
-  hipGraphExec_t exec = nullptr;
+
+  // ---- lanes: row ranges [b0, b0 + Bl) stepping concurrently (CCX_DEC_LANES overrides the default) ----
+  int nl = 1;
+  {
+    const char* e = getenv("CCX_DEC_LANES");
+    const int forced = e ? atoi(e) : 0;
+    if (forced >= 1) nl = forced;
+    else nl = B >= 144 ? 3 : (B >= 96 ? 2 : 1);   // measured at 192 sequences: 1 lane 316.8, 2 306.6, 3 303.0, 4 301.7 ms
+    if (nl > ccx_whisper::kMaxLanes) nl = ccx_whisper::kMaxLanes;
+    while (nl > 1 && B / nl < 16) nl--;
+  }
+  const std::vector<hipStream_t>* extra = nullptr;
+  if (nl > 1) {
+    extra = &lane_streams_for(w, stream, nl - 1);
+    if ((int)extra->size() + 1 < nl) nl = (int)extra->size() + 1;
+  }
+  struct Lane { int b0, B; hipStream_t s; hipGraphExec_t exec; };
+  Lane lanes[ccx_whisper::kMaxLanes];
+  {
+    const int per = ccx_cdiv(ccx_cdiv(B, nl), 16) * 16;   // lane sizes in multiples of one MFMA row tile
+    int b0 = 0, n = 0;
+    for (; n < nl && b0 < B; n++) {
+      lanes[n].b0 = b0; lanes[n].B = (b0 + per <= B) ? per : B - b0;
+      lanes[n].s = n == 0 ? stream : (*extra)[n - 1];
+      lanes[n].exec = nullptr;
+      b0 += lanes[n].B;
+    }
+    nl = n;
+  }
+  // the state upload was queued on `stream`: the other lanes start after it
+  CCX_HIP(ctx, hipEventRecord(w->own_event, stream));
+  for (int i = 1; i < nl; i++) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->own_event, 0));
+  auto step_lane = [&](int i, hipEvent_t stagger) -> int {
+    const Lane& L = lanes[i];
+    return dec_step(w, L.b0, L.B, w->dlogits + (long)L.b0 * ld, ld, true, sample_len, max_prompt, w->n_done + i, L.s, stagger);
+  };
+  // first step runs eagerly (also performs one-time kernel attribute setup outside of capture).  Lane i + 1
+  // starts when lane i reaches its first cross attention, which sets the stagger the later steps keep.
+  for (int i = 0; i < nl; i++) {
+    if (i > 0) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
+    TRY(step_lane(i, (i + 1 < nl) ? w->lane_start[i] : nullptr));
+    if (ctx->prof_on && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+  }
+  int step = 1;
   if (use_graph && total_steps > 1) {
-    auto it = w->graphs.find(key);
-    if (it != w->graphs.end()) exec = it->second;
-    else {
+    for (int i = 0; i < nl; i++) {
+      // graphs are specific to (lane rows, sample_len, max_prompt)
+      const long key = (((long)lanes[i].b0 * 4099 + lanes[i].B) * 4099 + sample_len) * 4099 + max_prompt;
+      auto it = w->graphs.find(key);
+      if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;
-      CCX_HIP(ctx, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      int rc = dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream);
-      hipError_t e = hipStreamEndCapture(stream, &graph);
+      hipGraphExec_t exec = nullptr;
+      CCX_HIP(ctx, hipStreamBeginCapture(lanes[i].s, hipStreamCaptureModeThreadLocal));
+      int rc = step_lane(i, nullptr);
+      hipError_t e = hipStreamEndCapture(lanes[i].s, &graph);
       if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
       if (e != hipSuccess) return ccx_fail(ctx, CCX_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
       e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       hipGraphDestroy(graph);
       if (e != hipSuccess) return ccx_fail(ctx, CCX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
       w->graphs[key] = exec;
+      lanes[i].exec = exec;
     }
   }
-  int n_done_host = 0;
-  while (step < total_steps) {
-    const int chunk = (total_steps - step < 16) ? total_steps - step : 16;
-    for (int i = 0; i < chunk; i++) {
-      if (exec) CCX_HIP(ctx, hipGraphLaunch(exec, stream));
-      else TRY(dec_step(w, B, w->dlogits, ld, true, sample_len, max_prompt, stream));
+  // Steps are queued in chunks; the done counters of chunk c are polled only after chunk c + 1 is queued,
+  // so no stream runs dry while the host waits.
+  const int kChunk = 8;
+  auto queue_chunk = [&](int c, int n) -> int {
+    for (int k = 0; k < n; k++)
+      for (int i = 0; i < nl; i++) {
+        if (lanes[i].exec) CCX_HIP(ctx, hipGraphLaunch(lanes[i].exec, lanes[i].s));   // ~50 us of host time per replay
+        else {
+          TRY(step_lane(i, nullptr));
+          // profiling mode (ccx_prof_enable) times every kernel with an event pair: keep the lanes apart so
+          // that the durations are those of the kernel alone, as rocprofv3 (which serialises replays) sees them
+          if (ctx->prof_on && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+        }
+      }
+    for (int i = 0; i < nl; i++) {
+      CCX_HIP(ctx, hipMemcpyAsync(&w->poll_host[(c & 1) * ccx_whisper::kMaxLanes + i], w->n_done + i, 4, hipMemcpyDeviceToHost, lanes[i].s));
+      CCX_HIP(ctx, hipEventRecord(w->lane_poll[c & 1][i], lanes[i].s));
     }
-    step += chunk;
-    CCX_HIP(ctx, hipMemcpyAsync(&n_done_host, w->n_done, 4, hipMemcpyDeviceToHost, stream));
-    CCX_HIP(ctx, hipStreamSynchronize(stream));
-    if (n_done_host >= B) break;
+    return CCX_OK;
+  };
+  auto chunk_done = [&](int c, bool* all) -> int {
+    *all = true;
+    for (int i = 0; i < nl; i++) {
+      CCX_HIP(ctx, hipEventSynchronize(w->lane_poll[c & 1][i]));
+      if (w->poll_host[(c & 1) * ccx_whisper::kMaxLanes + i] < lanes[i].B) *all = false;
+    }
+    return CCX_OK;
+  };
+  int c = 0;
+  bool pending = false;   // chunk c - 1 queued but not polled yet
+  while (step < total_steps) {
+    const int n = (total_steps - step < kChunk) ? total_steps - step : kChunk;
+    TRY(queue_chunk(c, n));
+    step += n;
+    if (pending) {
+      bool all;
+      TRY(chunk_done(c - 1, &all));
+      if (all) break;
+    }
+    pending = true;
+    c++;
+  }
+  // join the lanes back into `stream`
+  for (int i = 1; i < nl; i++) {
+    CCX_HIP(ctx, hipEventRecord(w->lane_start[i], lanes[i].s));
+    CCX_HIP(ctx, hipStreamWaitEvent(stream, w->lane_start[i], 0));
   }
   std::vector<DecSeqState> st(B);
   std::vector<int> gen((size_t)B * sample_len);
