@@ -77,6 +77,11 @@ PROTOTYPES = {
     "ccx_speaker_finalize": (_i, [_vp]),
     "ccx_speaker_embed": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64p, _ip, _vp, _vp]),
     "ccx_speaker_segment": (_i, [_vp, _vp, _i64p, _ip, _i, _vp, _i64, _ip, _vp]),
+    "ccx_resnet_create": (_i, [_vp, _i, _i64, _i, C.POINTER(_vp)]),
+    "ccx_resnet_destroy": (None, [_vp]),
+    "ccx_resnet_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i64]),
+    "ccx_resnet_finalize": (_i, [_vp]),
+    "ccx_resnet_embed": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _ip, _i, _vp, _vp]),
     "ccx_specgate_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
     "ccx_specgate_destroy": (None, [_vp]),
     "ccx_specgate_reduce": (_i, [_vp, _vp, _i64, _ip, _i, _f, _vp, _vp]),

@@ -12,14 +12,18 @@ enum GemmEpi {
   EPI_HEADS = 4,       // q/k (/v) scattered head-major for the attention kernels
   EPI_BF16_RELU = 5,   // out bf16 = relu(acc + bias)
   EPI_F32_GELU_POS = 6, // out f32 = gelu(acc + bias) + resid[row % resid_mod][n]   (conv2 + pos-emb)
-  EPI_BF16_LRELU_AFFINE = 7 // out bf16 = leaky_relu(acc + bias (+ resid)) * scale[n] + shift[n]  (TDNN conv + BatchNorm)
+  EPI_BF16_LRELU_AFFINE = 7, // out bf16 = leaky_relu(acc + bias (+ resid)) * scale[n] + shift[n]  (TDNN conv + BatchNorm)
+  EPI_BF16_ADD_RELU = 8  // out bf16 = relu(acc + bias + resid_bf16[out_row][n])   (ResNet basic block; resid may be null)
 };
 
 struct GemmParams {
   const bf16_t* A;   // [M, K] row-major, leading dimension lda (elements)
   const bf16_t* W;   // [N, K] row-major (torch Linear layout), leading dimension ldw
   long lda, ldw;
-  int M, N, K;       // K % 64 == 0; out must have ceil(N/128)*128 writable columns per row
+  int M, N, K;       // K % 64 == 0; N % 16 == 0 or the destination has ceil(N/16)*16 writable columns per row
+  // Accumulated taps (convolutions as shifted GEMMs): C = sum_t A[row + t*a_tap_stride elements][0..K) * W[n][t*K .. (t+1)*K).
+  // ntaps <= 1 is a plain GEMM.  W rows then hold ntaps*K elements (ldw >= ntaps*K).
+  int ntaps; long a_tap_stride;
   const float* bias; // [N] fp32 or nullptr
   void* out;         // bf16 or f32 depending on epilogue
   long ldo;
@@ -31,6 +35,10 @@ struct GemmParams {
   // output row remap: rows arrive in groups of rpb_in; group g row i -> g*rpb_out + i + roff,
   // rows with i >= rpb_valid are dropped.  rpb_in == 0 -> identity.
   int rpb_in, rpb_out, roff, rpb_valid;
+  // second level (images of padded rows): if img_rows_in > 0, group g = img*img_rows_in + r; rows with r >= img_rows_valid
+  // are dropped and the output group is img*img_rows_out + r.
+  int img_rows_in, img_rows_valid, img_rows_out;
+  const bf16_t* resid_bf16; long ldrb;   // EPI_BF16_ADD_RELU
   // EPI_HEADS
   bf16_t* hq; bf16_t* hk; bf16_t* hv;  // destinations for column blocks 0,1,2 (each d_model wide)
   int d_model, n_head;   // head_dim fixed to 64

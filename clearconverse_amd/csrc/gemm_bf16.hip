@@ -57,16 +57,19 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
     int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
     srcB[i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyB(r)) << 3);
   }
+  const int kt_per_tap = p.K / BK;
   auto stage = [&](int t, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
-    const int k0 = t * BK;
+    const int tap = t / kt_per_tap;                               // scalar: which shifted view of A
+    const long ka = (long)(t - tap * kt_per_tap) * BK + (long)tap * p.a_tap_stride;
+    const int kw = t * BK;                                        // W rows hold the taps back to back
 #pragma unroll
     for (int i = 0; i < NA; i++)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + k0), (lptr_t)(sA + (wave * NA + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + ka), (lptr_t)(sA + (wave * NA + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < NB; i++)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + k0), (lptr_t)(sB + (wave * NB + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kw), (lptr_t)(sB + (wave * NB + i) * 1024), 16, 0, 0);
   };
 
   // ---- per-lane LDS read offsets ----
@@ -81,7 +84,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
     offB[ks] = (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb) << 4);
   }
 
-  const int nt = p.K / BK;
+  const int nt = kt_per_tap * (p.ntaps > 1 ? p.ntaps : 1);
   stage(0, 0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and makes it visible to all waves
   for (int t = 0; t < nt; t++) {
@@ -112,13 +115,19 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
 
 __device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& valid) {
   if (p.rpb_in <= 0) { valid = true; return m; }
-  const int g = m / p.rpb_in, i = m - g * p.rpb_in;
+  int g = m / p.rpb_in;
+  const int i = m - g * p.rpb_in;
   valid = i < p.rpb_valid;
+  if (p.img_rows_in > 0) {
+    const int img = g / p.img_rows_in, r = g - img * p.img_rows_in;
+    valid = valid && r < p.img_rows_valid;
+    g = img * p.img_rows_out + r;
+  }
   return (long)g * p.rpb_out + i + p.roff;
 }
 
 template <int EPI, int WM, int WN, int MT>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4 * (MT == 4 ? 2 : 1)) void gemm_bf16_nt_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT == 4 ? 2 : 1) : 4) void gemm_bf16_nt_kernel(GemmParams p) {
   constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + TBN - 1) / TBN;
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4 * (MT == 4 ? 2 : 1)) vo
 
   // lane: row m = m0 + wr*64 + mt*16 + l15 ; columns nb .. nb+15, value index 4j+reg
   const int nb = n0 + wc * 64 + 16 * h;
+  if (EPI != EPI_HEADS && nb >= p.N) return;   // this lane's 16 columns lie wholly past N (narrow layers)
   float bias[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) bias[i] = 0.f;
@@ -227,7 +237,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4 * (MT == 4 ? 2 : 1)) vo
         v[i] = t * sc + sh;
       }
     }
-    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE) {
+    if (EPI == EPI_BF16_ADD_RELU) {
+      if (p.resid_bf16) {
+        const uint4* rp = (const uint4*)(p.resid_bf16 + orow * p.ldrb + nb);
+        const uint4 r0 = rp[0], r1 = rp[1];
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          v[2 * i] += __uint_as_float(rw[i] << 16);
+          v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
+    }
+    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
       if (EPI == EPI_BF16_GELU) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
@@ -278,8 +302,9 @@ static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream)
   {
     // algorithmic work: 2*M*N*K flops; bytes = A + W read once + output written once
     const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;  // output element size
-    ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * p.K,
-                      2.0 * ((double)p.M * p.K + (double)p.N * p.K) + obytes * p.M * (double)p.N);
+    const double kt = (double)p.K * (p.ntaps > 1 ? p.ntaps : 1);
+    ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * kt,
+                      2.0 * ((double)p.M * p.K + (double)p.N * kt) + obytes * p.M * (double)p.N);
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, WM, WN, MT>), dim3(tiles), dim3(WM * WN * 64), LDS, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
@@ -292,12 +317,12 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   // the 128x128 kernel (2 blocks per CU) otherwise.  CCX_GEMM_TILE=128|256 forces one for A/B measurements.
   static const int forced = [] { const char* e = getenv("CCX_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const long big_tiles = (long)ccx_cdiv(p.M, 256) * ccx_cdiv(p.N, 256);
-  // stores are not guarded along N: the destination must cover N rounded up to the tile width
   bool fits = p.N >= 256 && (p.N % 256 == 0 || p.N >= 1024);
   if (EPI == EPI_HEADS) fits = fits && p.N % 256 == 0 && p.d_model % 256 == 0;
-  else fits = fits && p.ldo >= (long)ccx_cdiv(p.N, 256) * 256;
   const bool big = fits && (forced == 256 || (forced != 128 && big_tiles >= 224));
   if (big) return launch_epi_geo<EPI, 2, 4, 8>(ctx, p, stream);
+  // narrow layers (ResNet 32/64 channels): 128 x 64 tiles, 2 waves, so that at most half a tile is idle
+  if (EPI != EPI_HEADS && p.N <= 64 && forced == 0) return launch_epi_geo<EPI, 2, 1, 4>(ctx, p, stream);
   return launch_epi_geo<EPI, 2, 2, 4>(ctx, p, stream);
 }
 
@@ -305,6 +330,7 @@ int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stre
   CCX_REQUIRE(ctx, p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   CCX_REQUIRE(ctx, p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
   CCX_REQUIRE(ctx, p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
+  CCX_REQUIRE(ctx, p.ntaps <= 1 || (p.a_tap_stride % 8 == 0 && p.ldw >= (long)p.ntaps * p.K), "gemm: bad tap layout");
   CCX_REQUIRE(ctx, ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: A/W must be 16-byte aligned");
   if (epi == EPI_HEADS) {
     CCX_REQUIRE(ctx, p.d_model % 128 == 0 && p.S > 0 && p.S % 4 == 0 && p.Spad >= p.S && p.Spad % 8 == 0,
@@ -312,7 +338,8 @@ int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stre
     CCX_REQUIRE(ctx, p.N % 128 == 0, "gemm heads: N must be a multiple of 128");
   } else {
     CCX_REQUIRE(ctx, p.out != nullptr && p.ldo % 8 == 0, "gemm: out null or ldo not a multiple of 8");
-    CCX_REQUIRE(ctx, p.ldo >= (long)ccx_cdiv(p.N, BN) * BN, "gemm: ldo=%ld must cover N rounded up to 128", p.ldo);
+    // each lane stores 16 consecutive columns; groups wholly past N are skipped
+    CCX_REQUIRE(ctx, p.ldo >= (long)ccx_cdiv(p.N, 16) * 16, "gemm: ldo=%ld must cover N rounded up to 16", p.ldo);
   }
   switch (epi) {
     case EPI_BF16: return launch_epi<EPI_BF16>(ctx, p, stream);
@@ -323,6 +350,7 @@ int ccx_launch_gemm(ccx_ctx* ctx, int epi, const GemmParams& p, hipStream_t stre
     case EPI_HEADS: return launch_epi<EPI_HEADS>(ctx, p, stream);
     case EPI_F32_GELU_POS: return launch_epi<EPI_F32_GELU_POS>(ctx, p, stream);
     case EPI_BF16_LRELU_AFFINE: return launch_epi<EPI_BF16_LRELU_AFFINE>(ctx, p, stream);
+    case EPI_BF16_ADD_RELU: return launch_epi<EPI_BF16_ADD_RELU>(ctx, p, stream);
   }
   return ccx_fail(ctx, CCX_ERR_ARG, "gemm: unknown epilogue %d", epi);
 }

@@ -112,6 +112,85 @@ class XVectorEmbedder(_SpeakerNet):
         return self.embed_batch([w.reshape(-1)])[0].cpu().numpy()
 
 
+class ResNetEmbedder:
+    """WeSpeaker ResNet-34 (`pyannote/wespeaker-voxceleb-resnet34-LM`), the embedding model inside the
+    reference's `pyannote/speaker-diarization-3.1` pipeline (/root/reference/back/api.py:788-792, called at
+    1056-1060 and 1124-1128).  `embed_chunks` embeds equal-length chunks; with `weights` it returns one
+    embedding per (chunk, mask) pair while the convolutional trunk runs once per chunk."""
+    DIM = 256
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], max_chunks: int = 96, max_samples: int = 160000, max_masks: int = 512,
+                 device: int = 0, ctx: Optional[_lib.Context] = None):
+        if not torch.cuda.is_available():
+            raise _lib.CcxError("speaker networks need a ROCm GPU: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.ctx = ctx or _lib.Context(device)
+        self.lib = self.ctx.lib
+        self.max_chunks, self.max_samples, self.max_masks = int(max_chunks), int(max_samples), int(max_masks)
+        h = C.c_void_p()
+        self.ctx.check(self.lib.ccx_resnet_create(self.ctx.handle, self.max_chunks, self.max_samples, self.max_masks, C.byref(h)),
+                       "ccx_resnet_create")
+        self.handle = h
+        for name, t in state_dict.items():
+            if not torch.is_tensor(t) or name.endswith("num_batches_tracked"):
+                continue
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            self.ctx.check(self.lib.ccx_resnet_set_tensor(self.handle, name.encode(), t.data_ptr(), t.numel()), f"set_tensor({name})")
+        self.ctx.check(self.lib.ccx_resnet_finalize(self.handle), "ccx_resnet_finalize")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ccx_resnet_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def embed_chunks(self, chunks: torch.Tensor, weights: Optional[torch.Tensor] = None,
+                     mask_chunk: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """chunks [n, N] f32 (16 kHz, equal lengths).  weights None -> [n, 256]; else weights [m, n_w] frame weights
+        and mask_chunk [m] (chunk index of each mask) -> [m, 256]."""
+        chunks = chunks.to(self.device, torch.float32).contiguous()
+        n, N = int(chunks.shape[0]), int(chunks.shape[1])
+        if weights is None:
+            out = torch.empty(n, self.DIM, device=self.device, dtype=torch.float32)
+            for i0 in range(0, n, min(self.max_chunks, self.max_masks)):
+                part = chunks[i0:i0 + min(self.max_chunks, self.max_masks)]
+                self.ctx.check(self.lib.ccx_resnet_embed(self.handle, part.data_ptr(), N, N, int(part.shape[0]), None, 0, None, 0,
+                                                         out[i0:].data_ptr(), _lib.current_stream_ptr()), "ccx_resnet_embed")
+            return out
+        weights = weights.to(self.device, torch.float32).contiguous()
+        mc = np.asarray(mask_chunk, dtype=np.int64)
+        if mc.shape[0] != weights.shape[0]:
+            raise _lib.CcxError("embed_chunks: one mask_chunk entry per weight row is required")
+        if mc.size and (np.any(np.diff(mc) < 0) or mc.min() < 0 or mc.max() >= n):
+            raise _lib.CcxError("embed_chunks: mask_chunk must be sorted and index existing chunks")
+        m, n_w = int(weights.shape[0]), int(weights.shape[1])
+        out = torch.empty(m, self.DIM, device=self.device, dtype=torch.float32)
+        ip = C.POINTER(C.c_int)
+        c0 = 0
+        while c0 < n:
+            # chunks [c0, c1) and their masks [j0, j1), both within capacity
+            c1 = min(n, c0 + self.max_chunks)
+            j0 = int(np.searchsorted(mc, c0, "left"))
+            while c1 > c0 + 1 and int(np.searchsorted(mc, c1, "left")) - j0 > self.max_masks:
+                c1 -= 1
+            j1 = int(np.searchsorted(mc, c1, "left"))
+            if j1 - j0 > self.max_masks:
+                raise _lib.CcxError("embed_chunks: a single chunk has more masks than max_masks")
+            if j1 > j0:
+                part = chunks[c0:c1]
+                local = (mc[j0:j1] - c0).astype(np.int32)
+                self.ctx.check(self.lib.ccx_resnet_embed(self.handle, part.data_ptr(), N, N, c1 - c0, weights[j0:j1].data_ptr(), n_w,
+                                                         local.ctypes.data_as(ip), j1 - j0, out[j0:j1].data_ptr(),
+                                                         _lib.current_stream_ptr()), "ccx_resnet_embed")
+            c0 = c1
+        return out
+
+
 class SegmentationNet(_SpeakerNet):
     """PyanNet: frames of per-class scores for each crop (SincNet frame rate: 1 frame per 270 samples)."""
 

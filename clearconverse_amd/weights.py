@@ -238,6 +238,47 @@ def synthetic_xvector_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+RESNET34_LAYERS = (3, 4, 6, 3)
+
+
+def synthetic_resnet34_state_dict(seed: int = 0, m_channels: int = 32, feat_dim: int = 80, embed_dim: int = 256) -> Dict[str, torch.Tensor]:
+    """`pyannote/wespeaker-voxceleb-resnet34-LM` key layout (resnet.conv1 / bn1 / layer{1..4}.{i}.conv{1,2} / bn{1,2} /
+    shortcut.{0,1} / seg_1) with seeded weights (He-scaled convolutions, mild BatchNorm statistics)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def bn(name, c):
+        sd[name + ".weight"] = 1 + 0.1 * torch.randn(c, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(c, generator=g)
+        sd[name + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+
+    def conv(name, cout, cin, k):
+        sd[name] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))
+
+    conv("resnet.conv1.weight", m_channels, 1, 3)
+    bn("resnet.bn1", m_channels)
+    cin = m_channels
+    for li, nblocks in enumerate(RESNET34_LAYERS, start=1):
+        cout = m_channels * (1 << (li - 1))
+        for bi in range(nblocks):
+            p = f"resnet.layer{li}.{bi}."
+            stride = 2 if (li > 1 and bi == 0) else 1
+            conv(p + "conv1.weight", cout, cin, 3)
+            bn(p + "bn1", cout)
+            conv(p + "conv2.weight", cout, cout, 3)
+            sd[p + "conv2.weight"] *= 0.5      # keeps the residual stream O(1..10) through 16 blocks
+            bn(p + "bn2", cout)
+            if stride != 1 or cin != cout:
+                conv(p + "shortcut.0.weight", cout, cin, 1)
+                bn(p + "shortcut.1", cout)
+            cin = cout
+    stats = cin * (feat_dim // 8) * 2
+    sd["resnet.seg_1.weight"] = torch.randn(embed_dim, stats, generator=g) / math.sqrt(stats)
+    sd["resnet.seg_1.bias"] = 0.1 * torch.randn(embed_dim, generator=g)
+    return sd
+
+
 def synthetic_pyannet_state_dict(n_classes: int = 7, seed: int = 0) -> Dict[str, torch.Tensor]:
     """PyanNet (pyannote/segmentation*) key layout with seeded weights: SincNet, 4 BiLSTM(128), 2 linear, classifier."""
     g = torch.Generator().manual_seed(seed)

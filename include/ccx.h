@@ -170,6 +170,24 @@ int ccx_speaker_embed(ccx_speaker* s, const float* wav_dev, const int64_t* offse
 int ccx_speaker_segment(ccx_speaker* s, const float* wav_dev, const int64_t* offsets, const int* n_samples, int n,
                         float* out_dev, int64_t out_capacity_rows, int* frames_out, void* stream);
 
+/* ---- WeSpeaker ResNet-34 speaker embedder: the embedding model inside self.diarization =
+ *      Pipeline.from_pretrained("pyannote/speaker-diarization-3.1"), reference back/api.py:788-792, called at
+ *      back/api.py:1056-1060 and 1124-1128 (one embedding per 10 s chunk and local speaker) ---------------- */
+typedef struct ccx_resnet ccx_resnet;
+/* max_samples: longest chunk of one call; max_masks: most (chunk, speaker) masks of one call */
+int ccx_resnet_create(ccx_ctx* ctx, int max_chunks, int64_t max_samples, int max_masks, ccx_resnet** out);
+void ccx_resnet_destroy(ccx_resnet* r);
+/* Tensors by checkpoint key (f32): "resnet.conv1.weight", "resnet.bn1.running_mean", "resnet.layer2.0.conv1.weight",
+ * "resnet.layer2.0.shortcut.0.weight", "resnet.layer2.0.shortcut.1.weight", ..., "resnet.seg_1.weight". */
+int ccx_resnet_set_tensor(ccx_resnet* r, const char* name, const float* data, int64_t numel);
+int ccx_resnet_finalize(ccx_resnet* r);
+/* wav_dev [n_chunks, stride] f32, every chunk n_samples long.  weights_dev NULL: one embedding per chunk, out_dev
+ * [n_chunks, 256] f32.  Else weights_dev [n_masks, n_w] f32 frame weights (any resolution, nearest-interpolated to
+ * the pooling frames) and mask_chunk [n_masks] (host: the chunk each mask pools over): out_dev [n_masks, 256].
+ * The convolutional trunk runs once per chunk. */
+int ccx_resnet_embed(ccx_resnet* r, const float* wav_dev, int64_t stride, int n_samples, int n_chunks, const float* weights_dev,
+                     int n_w, const int* mask_chunk, int n_masks, float* out_dev, void* stream);
+
 /* ---- stationary spectral-gate denoiser (replaces nr.reduce_noise(y=, sr=, stationary=True,
  *      prop_decrease=), reference back/api.py:349 and 832-833) ---------------------------------------- */
 typedef struct ccx_specgate ccx_specgate;

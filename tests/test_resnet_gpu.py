@@ -1,0 +1,74 @@
+"""GPU parity of the WeSpeaker ResNet-34 embedder (K21, csrc/resnet.hip) against oracle/wespeaker_ref.py,
+through the C ABI (ccx_resnet_*).  Tolerance: rel-L2 <= 3e-2 on the embedding (bf16 activations through
+33 convolutions against the fp32 restatement; SURVEY.md 8c states 1e-2 per bf16 tensor)."""
+import numpy as np
+import pytest
+import torch
+
+from clearconverse_amd.audio import synthetic_clip
+from clearconverse_amd.weights import synthetic_resnet34_state_dict
+from oracle import wespeaker_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-2
+
+
+def _clip(seed, n, off=0):
+    return np.asarray(synthetic_clip(seed), dtype=np.float32)[off:off + n]
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def net(ccx_ctx):
+    from clearconverse_amd.speaker import ResNetEmbedder
+    sd = synthetic_resnet34_state_dict(0)
+    return sd, ResNetEmbedder(sd, max_chunks=8, max_samples=160000, max_masks=32, ctx=ccx_ctx)
+
+
+def test_unweighted_embeddings_match_oracle(net):
+    sd, emb = net
+    waves = np.stack([_clip(11, 32000), _clip(12, 32000, 16000), _clip(13, 32000, 40000)])
+    got = emb.embed_chunks(torch.from_numpy(waves)).cpu().numpy()
+    want = R.resnet_embed(sd, waves)
+    assert got.shape == want.shape == (3, 256)
+    for i in range(3):
+        assert _rel(got[i], want[i]) < TOL, (i, _rel(got[i], want[i]))
+
+
+def test_masked_embeddings_share_the_trunk(net):
+    sd, emb = net
+    waves = np.stack([_clip(21, 48000), _clip(22, 48000, 8000)])
+    rng = np.random.default_rng(0)
+    w = (rng.random((5, 117)) > 0.4).astype(np.float32)
+    w[2] = rng.random(117).astype(np.float32)              # soft weights
+    mc = np.array([0, 0, 0, 1, 1])
+    got = emb.embed_chunks(torch.from_numpy(waves), torch.from_numpy(w), mc).cpu().numpy()
+    want = R.resnet_embed(sd, waves, w, mc)
+    for j in range(5):
+        assert _rel(got[j], want[j]) < TOL, (j, _rel(got[j], want[j]))
+
+
+def test_ten_second_chunk_and_geometry_change(net):
+    sd, emb = net
+    wave = _clip(31, 160000)[None]                          # the diarization pipeline's chunk length: 998 frames
+    got = emb.embed_chunks(torch.from_numpy(wave)).cpu().numpy()
+    want = R.resnet_embed(sd, wave)
+    assert _rel(got[0], want[0]) < TOL, _rel(got[0], want[0])
+    # a shorter call afterwards moves the halo cells: results must not depend on the previous geometry
+    short = np.stack([_clip(32, 24000)])
+    got2 = emb.embed_chunks(torch.from_numpy(short)).cpu().numpy()
+    assert _rel(got2[0], R.resnet_embed(sd, short)[0]) < TOL
+
+
+def test_capacity_and_argument_errors(net):
+    from clearconverse_amd import _lib
+    _, emb = net
+    with pytest.raises(_lib.CcxError):
+        emb.embed_chunks(torch.zeros(1, 161000))            # longer than max_samples
+    with pytest.raises(_lib.CcxError):
+        emb.embed_chunks(torch.zeros(1, 1000))              # too short for two pooled frames
+    with pytest.raises(_lib.CcxError):
+        emb.embed_chunks(torch.zeros(2, 32000), torch.ones(2, 10), [1, 0])   # unsorted mask_chunk
