@@ -71,11 +71,12 @@ def cpu_baseline_whisper(dims, sd, clip, rules, threads, tokens):
 
 def cpu_baseline_pipeline(models_sd, clip, rules, threads):
     """Oracle op timings on bounded samples, scaled by the op counts of ONE 30 s clip under the pinned
-    schedule (6 Whisper calls x (encode + 224 tokens), 4 separator regions (18 s), 107.6 s of x-vector input
-    + 63 x 10 s diarization crops, 51 x 5 s VAD + 21 x 10 s segmentation chunks, 58 s through the gate)."""
-    from oracle import pyannote_ref as P, sepformer_ref as S, spectral_gate_ref as G, whisper_ref as R
+    schedule (6 Whisper calls x (encode + 224 tokens), 4 separator regions (18 s), 107.6 s of x-vector input,
+    63 x 10 s ResNet-34 diarization crops (the reference embeds every (chunk, local speaker) pair separately),
+    51 x 5 s VAD + 21 x 10 s segmentation chunks, 58 s through the gate)."""
+    from oracle import pyannote_ref as P, sepformer_ref as S, spectral_gate_ref as G, wespeaker_ref as W, whisper_ref as R
     torch.set_num_threads(threads)
-    wd, wsd, sdims, ssd, xsd, psd = models_sd
+    wd, wsd, sdims, ssd, xsd, psd, rsd = models_sd
     w = cpu_baseline_whisper(wd, wsd, clip[: 16000 * 6], rules, threads, tokens=24)
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -85,6 +86,9 @@ def cpu_baseline_pipeline(models_sd, clip, rules, threads):
         for _ in range(4):
             P.xvector_forward(xsd, torch.from_numpy(clip[None, : 12800]))
         t_xvec_per_s = (time.perf_counter() - t0) / (4 * 0.8)
+        t0 = time.perf_counter()
+        W.resnet_embed(rsd, clip[None, : 16000 * 2])
+        t_res_per_s = (time.perf_counter() - t0) / 2.0
         osd = dict(psd); osd["powerset"] = torch.tensor(1)
         t0 = time.perf_counter()
         P.pyannet_forward(osd, torch.from_numpy(clip[None, None, : 16000 * 5]))
@@ -92,10 +96,10 @@ def cpu_baseline_pipeline(models_sd, clip, rules, threads):
     t0 = time.perf_counter()
     G.reduce_noise(clip, 16000, 0.5)
     t_gate_per_s = (time.perf_counter() - t0) / 30.0
-    t_clip = (6 * (w["t_enc"] + 224 * w["t_tok"]) + 18.0 * t_sep_per_s + (107.6 + 630.0) * t_xvec_per_s
+    t_clip = (6 * (w["t_enc"] + 224 * w["t_tok"]) + 18.0 * t_sep_per_s + 107.6 * t_xvec_per_s + 630.0 * t_res_per_s
               + (51 * 5 + 21 * 10) * t_seg_per_s + 58.0 * t_gate_per_s)
     sample = (f"timed samples (fp32 torch/scipy oracle): 1 Whisper window encode {w['t_enc']:.1f} s + 24 greedy tokens "
-              f"({w['t_tok'] * 1e3:.0f} ms/token), 2 s separator, 4 x 0.8 s x-vector, 5 s PyanNet, 30 s spectral gate; "
+              f"({w['t_tok'] * 1e3:.0f} ms/token), 2 s separator, 4 x 0.8 s x-vector, 2 s ResNet-34, 5 s PyanNet, 30 s spectral gate; "
               f"scaled by one clip's op counts under the pinned schedule -> {t_clip:.0f} s per 30 s clip")
     return 30.0 / t_clip, sample
 
@@ -129,7 +133,8 @@ def main():
     from clearconverse_amd.batch import BatchPipeline, gather_transcripts
     from clearconverse_amd.tokenizer import DecodeRules
     from clearconverse_amd.weights import (SepDims, WhisperDims, find_whisper_checkpoint, synthetic_pyannet_state_dict,
-                                           synthetic_sepformer_state_dict, synthetic_whisper_state_dict, synthetic_xvector_state_dict)
+                                           synthetic_resnet34_state_dict, synthetic_sepformer_state_dict, synthetic_whisper_state_dict,
+                                           synthetic_xvector_state_dict)
 
     pipeline = args.workload == "pipeline"
     B = args.batch or (32 if pipeline else 8)
@@ -143,9 +148,22 @@ def main():
     clips = [synthetic_clip(rank + world * i, 30.0) for i in range(B)]
     audio = torch.from_numpy(np.stack(clips)).cuda(local_rank).contiguous()   # resident in HBM before timing
 
+    t_load0 = time.perf_counter()
+    bcast_ms = None
     if pipeline:
-        from clearconverse_amd.models import load_models
-        models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0)
+        from clearconverse_amd.batch import broadcast_weights
+        from clearconverse_amd.models import build_state_dicts, load_models
+        # C1: rank 0 reads / generates the weights, ONE RCCL broadcast of the packed blob, every rank
+        # uploads its replica.  Outside the timed region; reported as weight_broadcast_ms / model_load_ms.
+        sds = build_state_dicts(None, seed=0) if rank == 0 else None
+        if dist is not None:
+            torch.cuda.synchronize(); dist.barrier()
+            tb = time.perf_counter()
+            sds = broadcast_weights(sds, src=0, device=torch.device("cuda", local_rank))
+            torch.cuda.synchronize()
+            bcast_ms = (time.perf_counter() - tb) * 1e3
+        models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0, state_dicts=sds)
+        del sds
         sd = None
         bp = BatchPipeline(models, whisper_group=args.whisper_group, sample_len=args.sample_len)
 
@@ -164,6 +182,8 @@ def main():
             recs = model.decode_greedy(prompts, sample_len=args.sample_len)
             return dict(records=recs, tokens=sum(len(r["tokens"]) for r in recs), whisper_calls=B)
 
+    torch.cuda.synchronize()
+    load_ms = (time.perf_counter() - t_load0) * 1e3
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -269,7 +289,7 @@ def main():
                 sdims = SepDims()
                 msd = (dims, ck[1] if ck is not None else synthetic_whisper_state_dict(dims, seed=0), sdims,
                        synthetic_sepformer_state_dict(sdims, seed=1), synthetic_xvector_state_dict(seed=2),
-                       synthetic_pyannet_state_dict(7, seed=3))
+                       synthetic_pyannet_state_dict(7, seed=3), synthetic_resnet34_state_dict(seed=5))
                 xrt, sample = cpu_baseline_pipeline(msd, clips[0], rules, threads)
             else:
                 w = cpu_baseline_whisper(dims, sd, clips[0], rules, threads, tokens=args.sample_len)
@@ -285,8 +305,8 @@ def main():
                "encoder_gflop_per_window": round((enc_f + cross_f) / 1e9, 1)}
         if pipeline:
             cfg["schedule"] = ("pinned synthetic schedule (SURVEY.md 8d): per clip 2 regular + 2 overlap-bearing segments -> "
-                               "6 Whisper windows, 4 separator regions, 62 x-vector crops + diarization crops, VAD and "
-                               "diarization computed but not steering")
+                               "6 Whisper windows, 4 separator regions, 62 x-vector crops; VAD (51 x 5 s chunks) and diarization "
+                               "(21 x 10 s segmentation chunks + ResNet-34 embeddings of their local speakers) computed but not steering")
             cfg["whisper_group"] = args.whisper_group
             cfg["stage_ms_per_step"] = {k: round(v, 2) for k, v in bp.stage_ms.items()} if bp.stage_ms else None
         out = {
@@ -307,6 +327,8 @@ def main():
             "roofline_mfma": roof_mfma,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": stage_ms,
+            "model_load_ms": round(load_ms, 1),
+            "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 1),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -173,6 +173,55 @@ def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:
     return [i for i in range(n_clips) if i % world == rank]
 
 
+def broadcast_weights(state_dicts: Optional[dict], src: int = 0, device="cpu") -> dict:
+    """The start-of-job collective (C1): rank `src` holds the weights of every model
+    (models.build_state_dicts); all tensors are packed into ONE byte blob and sent with ONE broadcast (RCCL: a direct
+    1 -> N-1 send over the xGMI links), the small manifest (names / shapes / dtypes / non-tensor entries) as an object
+    broadcast before it.  Returns the same nested dict on every rank (tensors are views of the received blob)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if state_dicts is None:
+            raise ValueError("broadcast_weights: no process group and no local weights")
+        return state_dicts
+    rank = dist.get_rank()
+    manifest, parts, off = None, [], 0
+    if rank == src:
+        if state_dicts is None:
+            raise ValueError("broadcast_weights: the source rank needs the weights")
+        manifest = {"plain": {}, "tensors": []}
+        for model, sd in state_dicts.items():
+            if not isinstance(sd, dict) or not any(torch.is_tensor(v) for v in sd.values()):
+                manifest["plain"][model] = sd
+                continue
+            for key, t in sd.items():
+                if not torch.is_tensor(t):
+                    manifest["tensors"].append((model, key, None, None, None, 0, t))
+                    continue
+                t = t.detach().contiguous().cpu()
+                nbytes = t.numel() * t.element_size()
+                manifest["tensors"].append((model, key, tuple(t.shape), str(t.dtype).replace("torch.", ""), off, nbytes, None))
+                parts.append(t.reshape(-1).view(torch.uint8))
+                pad = -nbytes % 16                     # keep every tensor 16-byte aligned inside the blob
+                if pad:
+                    parts.append(torch.zeros(pad, dtype=torch.uint8))
+                off += nbytes + pad
+        manifest["total"] = off
+    box = [manifest]
+    dist.broadcast_object_list(box, src=src)
+    manifest = box[0]
+    if rank == src:
+        blob = (torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8)).to(device)
+    else:
+        blob = torch.empty(manifest["total"], dtype=torch.uint8, device=device)
+    if manifest["total"]:
+        dist.broadcast(blob, src=src)
+    out: dict = dict(manifest["plain"])
+    for model, key, shape, dtype, o, nbytes, plain in manifest["tensors"]:
+        d = out.setdefault(model, {})
+        d[key] = plain if shape is None else blob[o:o + nbytes].view(getattr(torch, dtype)).reshape(shape)
+    return out
+
+
 def gather_transcripts(records: List[dict], sample_len: int, eot: int, device) -> Optional[torch.Tensor]:
     """All-gather of fixed-size token records over RCCL (xGMI): the one data-path collective (C2)."""
     import torch.distributed as dist

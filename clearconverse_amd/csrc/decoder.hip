@@ -17,6 +17,7 @@
 //  * dec_select_kernel: SuppressBlank / SuppressTokens / ApplyTimestampRules + greedy argmax +
 //    running sum-logprob + no-speech probability (openai-whisper decoding.py, restated in
 //    oracle/whisper_ref.py) -- one block per sequence, device-side state machine.
+#include <string>
 #include "decoder.h"
 
 // ------------------------------------------------------------------------------------------
@@ -417,7 +418,10 @@ static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ks
   dim3 grid(ccx_cdiv(p.N, BN), ccx_cdiv(p.M, MROWS), ksplit);
   {
     // weight-streaming GEMV: algorithmic bytes = the weight matrix once (+ small activations)
-    ccx_prof_scope ps(ctx, stream, "dec_linear_kernel", 2.0 * p.M * (double)p.N * p.K,
+    // labelled like rocprofv3 labels the instantiation, so that both rank the same kernels
+    static const std::string label = "dec_linear_kernel<" + std::to_string(MT) + ", " + std::to_string(NT) + ", " + std::to_string(KMAX) +
+                                     ", " + std::to_string(ACT) + ", " + std::to_string(EPI) + ">";
+    ccx_prof_scope ps(ctx, stream, label.c_str(), 2.0 * p.M * (double)p.N * p.K,
                       2.0 * (double)p.N * p.K + 2.0 * p.M * ((double)p.K + p.N));
     hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI>), grid, dim3(256), lds, stream, p);
   }

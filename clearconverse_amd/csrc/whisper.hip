@@ -682,13 +682,14 @@ int cross_split(int B, int H) {
   // enough blocks to fill the chip, and <= 256 keys per block (one 64-key chunk per wave)
   int ns = ccx_cdiv(512, B * H);
   if (ns < 6) ns = 6;
+  if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
   if (B > 16) {
-    // many sequences: CCX_CROSS_SPLIT=n overrides (1 = whole key range per block, no partials / combine)
+    // many sequences: CCX_CROSS_SPLIT=n overrides (1 = whole key range per block, no partials / combine).  Measured at
+    // 64 sequences per lane: 6 splits 54.5 us per launch, 8 splits 56.8 us (a wave then owns 47 of a chunk's 64 keys).
     const char* e = getenv("CCX_CROSS_SPLIT");
     const int forced = e ? atoi(e) : 0;
-    if (forced >= 1) ns = forced;
+    if (forced >= 1 && forced <= ccx_whisper::kCrossSplitMax) ns = forced;
   }
-  if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
   return ns;
 }
 
@@ -920,7 +921,7 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
   for (int i = 0; i < nl; i++) {
     if (i > 0) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
     TRY(step_lane(i, (i + 1 < nl) ? w->lane_start[i] : nullptr));
-    if (ctx->prof_on && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+    if (ctx->prof_on && !use_graph && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
   }
   int step = 1;
   if (use_graph && total_steps > 1) {
@@ -952,9 +953,9 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
         if (lanes[i].exec) CCX_HIP(ctx, hipGraphLaunch(lanes[i].exec, lanes[i].s));   // ~50 us of host time per replay
         else {
           TRY(step_lane(i, nullptr));
-          // profiling mode (ccx_prof_enable) times every kernel with an event pair: keep the lanes apart so
+          // eager profiling runs (ccx_prof_enable + CCX_NO_GRAPH) time every kernel with an event pair: keep the lanes apart so
           // that the durations are those of the kernel alone, as rocprofv3 (which serialises replays) sees them
-          if (ctx->prof_on && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+          if (ctx->prof_on && !use_graph && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
         }
       }
     for (int i = 0; i < nl; i++) {

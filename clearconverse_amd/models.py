@@ -15,19 +15,18 @@ from . import _lib
 from .denoise import SpectralGate
 from .pipelines import SpeakerDiarization, VoiceActivityDetection
 from .separator import SepformerSeparator
-from .speaker import SegmentationNet, XVectorEmbedder
+from .speaker import ResNetEmbedder, SegmentationNet, XVectorEmbedder
 from .weights import (SepDims, WhisperDims, find_whisper_checkpoint, synthetic_pyannet_state_dict,
-                      synthetic_sepformer_state_dict, synthetic_whisper_state_dict, synthetic_xvector_state_dict)
+                      synthetic_resnet34_state_dict, synthetic_sepformer_state_dict, synthetic_whisper_state_dict,
+                      synthetic_xvector_state_dict)
 from .whisper import WhisperModel
 
 
-def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
-                whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
-                sep_tokens: int = 160_000, max_crops: int = 256) -> Dict[str, object]:
-    if not torch.cuda.is_available():
-        raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
-    dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
-    ctx = ctx or _lib.Context(dev_index)
+def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None,
+                      seed: int = 0) -> Dict[str, object]:
+    """Every weight of the path as host tensors: the real Whisper checkpoint when MODEL_CACHE_DIR holds one, seeded
+    synthetic weights of the same architectures otherwise.  In a multi-GPU job rank 0 calls this and the result
+    travels by ONE broadcast (batch.broadcast_weights)."""
     size = getattr(config, "whisper_model_size", "small.en") if config is not None else "small.en"
     ck = find_whisper_checkpoint(size) if whisper_dims is None else None
     if ck is not None:
@@ -35,24 +34,50 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     else:
         wd = whisper_dims or WhisperDims.small_en()
         wsd = synthetic_whisper_state_dict(wd, seed=seed)
+    sd_ = sep_dims or SepDims()
+    return {
+        "whisper_dims": dict(wd.__dict__), "whisper": wsd, "whisper_source": "checkpoint" if ck is not None else f"synthetic-seed{seed}",
+        "sep_dims": dict(sd_.__dict__), "sepformer": synthetic_sepformer_state_dict(sd_, seed=seed + 1),
+        "xvector": synthetic_xvector_state_dict(seed=seed + 2),
+        "pyannet_diar": synthetic_pyannet_state_dict(7, seed=seed + 3),
+        "pyannet_vad": synthetic_pyannet_state_dict(3, seed=seed + 4),
+        "resnet34": synthetic_resnet34_state_dict(seed=seed + 5),
+    }
+
+
+def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
+                whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
+                sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None) -> Dict[str, object]:
+    if not torch.cuda.is_available():
+        raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
+    dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
+    ctx = ctx or _lib.Context(dev_index)
+    W = state_dicts if state_dicts is not None else build_state_dicts(config, whisper_dims, sep_dims, seed)
+    wd, wsd = WhisperDims(**W["whisper_dims"]), W["whisper"]
+    sd_ = SepDims(**W["sep_dims"])
     whisper = WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds)
     sd_ = sep_dims or SepDims()
-    separator = SepformerSeparator(sd_, synthetic_sepformer_state_dict(sd_, seed=seed + 1), max_tokens=sep_tokens, max_utts=64,
+    separator = SepformerSeparator(sd_, W["sepformer"], max_tokens=sep_tokens, max_utts=64,
                                    device=dev_index, ctx=ctx)
-    embedder = XVectorEmbedder(synthetic_xvector_state_dict(seed=seed + 2), max_crops=max_crops, max_samples=16000 * 1200,
+    embedder = XVectorEmbedder(W["xvector"], max_crops=max_crops, max_samples=16000 * 1200,
                                device=dev_index, ctx=ctx)
-    seg_diar = SegmentationNet(synthetic_pyannet_state_dict(7, seed=seed + 3), n_classes=7, powerset=True, max_crops=max_crops,
+    # embedding model of the diarization pipeline (speaker-diarization-3.1 uses WeSpeaker ResNet-34, not pyannote/embedding)
+    diar_embedder = ResNetEmbedder(W["resnet34"], max_chunks=96, max_samples=160000, max_masks=512,
+                                   device=dev_index, ctx=ctx)
+    seg_diar = SegmentationNet(W["pyannet_diar"], n_classes=7, powerset=True, max_crops=max_crops,
                                max_samples=16000 * 1200, device=dev_index, ctx=ctx)
-    seg_vad = SegmentationNet(synthetic_pyannet_state_dict(3, seed=seed + 4), n_classes=3, powerset=False, max_crops=max_crops,
+    seg_vad = SegmentationNet(W["pyannet_vad"], n_classes=3, powerset=False, max_crops=max_crops,
                               max_samples=16000 * 1200, device=dev_index, ctx=ctx)
     gate = SpectralGate(max_samples=480000, max_clips=32, device=dev_index, ctx=ctx)
     return {
         "ctx": ctx,
+        "weights_source": W.get("whisper_source", "given"),
         "whisper_model": whisper,
         "separator": separator,
         "embedding_model": embedder,
         "vad_pipeline": VoiceActivityDetection(seg_vad, batch=max_crops),
-        "diarization": SpeakerDiarization(seg_diar, embedder, batch=max_crops),
+        "diarization": SpeakerDiarization(seg_diar, diar_embedder, batch=max_crops),
+        "diarization_embedder": diar_embedder,
         "denoiser": gate,
         "segmentation_vad": seg_vad,
         "segmentation_diar": seg_diar,

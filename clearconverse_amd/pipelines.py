@@ -284,10 +284,19 @@ class SpeakerDiarization:
                     clean = act & alone
                     w = clean if clean.sum() >= 0.5 * act.sum() else act
                     keys.append((ci, sp))
-                    e_crops.append(crops[i0 + ci])
+                    e_crops.append(i0 + ci)
                     e_weights.append(torch.from_numpy(w.astype(np.float32)))
             per_item.append((starts, multi, keys))
-        embs = self.emb.embed_batch(e_crops, weights=e_weights).cpu().numpy() if e_crops else np.zeros((0, 512), dtype=np.float32)
+        if not e_crops:
+            embs = np.zeros((0, getattr(self.emb, "DIM", 512)), dtype=np.float32)
+        elif hasattr(self.emb, "embed_chunks"):
+            # chunk-level embedder (WeSpeaker ResNet-34): the trunk runs once per window, pooling once per local speaker
+            used = sorted(set(e_crops))
+            where = {g: k for k, g in enumerate(used)}
+            embs = self.emb.embed_chunks(torch.stack([crops[g] for g in used]), torch.stack(e_weights),
+                                         [where[g] for g in e_crops]).cpu().numpy()
+        else:
+            embs = self.emb.embed_batch([crops[g] for g in e_crops], weights=e_weights).cpu().numpy()
         anns, e0 = [], 0
         for x, it in zip(xs, per_item):
             if it is None or not it[2]:
