@@ -59,6 +59,10 @@ struct DecSelectParams {
   int eot, blank, no_speech, timestamp_begin, max_initial_ts;
   // next-step embedding written by the select kernel: x[b] = tok_emb[next] + pos_emb[pos]
   const float* tok_emb; const float* pos_emb; float* x; int D;
+  // sampling (GreedyDecoder.update with temperature > 0): sample_cfg = {float temperature, u32 seed_lo, u32 seed_hi} in
+  // device memory (so that a captured step graph serves every temperature / seed); row0 = batch row of sequence 0 of
+  // this launch (lanes), so that the noise of a sequence does not depend on how the batch is split
+  const unsigned* sample_cfg; int row0;
 };
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,

@@ -638,6 +638,23 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 // into registers (13 float4 per thread, all loads issued before any use) together with the
 // suppress mask; every reduction then runs out of registers.  The kernel also writes the input
 // embedding of the NEXT step (token + position), so the step chain needs no separate embed launch.
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so every (seed, sequence, step, vocabulary quad) has its own
+// four 32-bit draws regardless of launch geometry.  oracle/whisper_ref.py::philox4x32 is the same function in numpy.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * ctr.x, p1 = (unsigned long long)0xCD9E8D57u * ctr.z;
+    ctr = make_uint4((unsigned)(p1 >> 32) ^ ctr.y ^ key.x, (unsigned)p1, (unsigned)(p0 >> 32) ^ ctr.w ^ key.y, (unsigned)p0);
+    key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+// standard Gumbel noise from a 32-bit draw: u = (x + 0.5) / 2^32 in (0, 1), g = -log(-log(u))
+__device__ __forceinline__ float gumbel_from_u32(unsigned x) {
+  const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);   // 24 bits: exact in fp32, never 0 or 1
+  return -logf(-logf(u));
+}
+
 #define SEL_V4 13
 __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   __shared__ float sh[16];
@@ -776,17 +793,50 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   se_text = block_reduce_sum(se_text, sh);
   se_ts = block_reduce_sum(se_ts, sh);
 
+  // timestamp_logprob > max_text_token_logprob  <=>  lse_ts > max_text (same normaliser)
+  const float lse_ts = (se_ts > 0.f) ? mx_all + logf(se_ts) : -INFINITY;
+  const bool force_ts = lse_ts > bt;
+  const float lse = force_ts ? lse_ts : mx_all + logf(se_text + se_ts);   // log-normaliser of the re-filtered logits
+
+  // ---- temperature > 0: Categorical(logits / T) by the Gumbel-max trick (argmax of logits / T + Gumbel noise) ----
+  const float temperature = __uint_as_float(p.sample_cfg[0]);
+  int samp = -1; float samp_logit = 0.f;
+  if (temperature > 0.f) {
+    const uint2 key = make_uint2(p.sample_cfg[1], p.sample_cfg[2]);
+    const float inv_t = 1.0f / temperature;
+    float best = -INFINITY, best_logit = -INFINITY; int best_i = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < SEL_V4; i++) {
+      const int v0 = tid * 4 + i * 4096;
+      const uint4 r = philox4x32_10(make_uint4((unsigned)(v0 >> 2), (unsigned)(p.row0 + b), (unsigned)i_gen, 0u), key);
+      const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int v = v0 + j;
+        const float x = (force_ts && v < tsb) ? -INFINITY : val[4 * i + j];
+        const float sc = x * inv_t + gumbel_from_u32(rr[j]);      // -inf stays -inf
+        if (sc > best) { best = sc; best_i = v; best_logit = x; }
+      }
+    }
+    float ov; int oi;
+    block_argmax(best, best_i, ov, oi);
+    samp = oi;
+    __syncthreads();
+    if (best_i == samp && best == ov) sh[0] = best_logit;         // exactly one thread owns the winner
+    __syncthreads();
+    samp_logit = sh[0];
+  }
+
   if (tid == 0) {
-    // timestamp_logprob > max_text_token_logprob  <=>  lse_ts > max_text (same normaliser)
-    const float lse_ts = (se_ts > 0.f) ? mx_all + logf(se_ts) : -INFINITY;
-    const bool force_ts = lse_ts > bt;
     int next; float logprob;
-    if (force_ts) {
+    if (samp >= 0) {
+      next = samp;
+      logprob = samp_logit - lse;
+    } else if (force_ts) {
       next = is;
-      logprob = bs - lse_ts;  // log_softmax over the re-filtered logits (text banned)
+      logprob = bs - lse;   // log_softmax over the re-filtered logits (text banned)
     } else {
       if (bt > bs || (bt == bs && it < is)) next = it; else next = is;
-      const float lse = mx_all + logf(se_text + se_ts);
       logprob = fmaxf(bt, bs) - lse;
     }
     s.sum_logprob += logprob;

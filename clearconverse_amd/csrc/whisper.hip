@@ -102,6 +102,7 @@ struct ccx_whisper {
   float *dx = nullptr, *dx2 = nullptr, *pend = nullptr, *dq = nullptr, *dlogits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   bf16_t *dattn = nullptr, *dffn = nullptr, *dxn = nullptr;
   int *cur_tok = nullptr, *pos = nullptr, *prompt = nullptr, *gen = nullptr, *n_done = nullptr;
+  unsigned* sample_cfg = nullptr;   // {temperature bits, seed lo, seed hi, 0}: read by the select kernel every step
   DecSeqState* state = nullptr;
   int max_prompt_cap = 0, sample_cap = 0;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
@@ -500,6 +501,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   TRY(dev_alloc(w, &w->cur_tok, (size_t)B, true));
   TRY(dev_alloc(w, &w->pos, (size_t)B, true));
   TRY(dev_alloc(w, &w->n_done, (size_t)4, true));
+  TRY(dev_alloc(w, &w->sample_cfg, (size_t)4, true));
   TRY(dev_alloc(w, &w->state, (size_t)B, true));
   w->max_prompt_cap = d.n_text_ctx;
   w->sample_cap = d.n_text_ctx;
@@ -802,13 +804,14 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
     sp.max_initial_ts = w->rules.max_initial_timestamp_index;
     sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx + ro * D; sp.D = D;
+    sp.sample_cfg = w->sample_cfg; sp.row0 = b0;
     TRY(ccx_launch_dec_select(ctx, sp, B, stream));
   }
   return CCX_OK;
 }
 
 int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
-                        hipStream_t stream) {
+                        float temperature, uint64_t seed, hipStream_t stream) {
   std::vector<DecSeqState> st(B);
   std::vector<int> tok(B), ps(B, 0);
   for (int b = 0; b < B; b++) {
@@ -822,6 +825,9 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
   CCX_HIP(w->ctx, hipMemcpyAsync(w->pos, ps.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->prompt, prompt_ids, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, 16, stream));
+  unsigned cfg[4] = {0u, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), 0u};
+  memcpy(&cfg[0], &temperature, 4);
+  CCX_HIP(w->ctx, hipMemcpyAsync(w->sample_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, stream));
   // embedding of the first token; later steps get theirs from the select kernel
   TRY(ccx_launch_dec_embed(w->ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, w->d.n_text_state, stream));
   CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host vectors go out of scope
@@ -842,7 +848,7 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
     CCX_REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < w->d.n_vocab, "decoder_logits: token id %d out of range", tokens[i]);
   std::vector<int32_t> lens(B, T + 1);  // never leaves the prompt phase: every step feeds tokens[b][pos]
   // prompt buffer rows are `T` wide here
-  TRY(upload_decode_state(w, tokens, lens.data(), T, B, stream));
+  TRY(upload_decode_state(w, tokens, lens.data(), T, B, 0.f, 0, stream));
   const long V = w->d.n_vocab;
   for (int t = 0; t < T; t++) {
     // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it
@@ -854,7 +860,15 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
 int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
                               int sample_len, int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
                               float* no_speech_prob_out, void* stream_) {
+  return ccx_whisper_decode(w, prompt_ids, prompt_lens, max_prompt, B, sample_len, 0.f, 0, tokens_out, n_tokens_out, sum_logprob_out,
+                            no_speech_prob_out, stream_);
+}
+
+int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B, int sample_len,
+                       float temperature, uint64_t seed, int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
+                       float* no_speech_prob_out, void* stream_) {
   if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, temperature >= 0.f && temperature == temperature, "decode: temperature must be >= 0");
   hipStream_t stream = (hipStream_t)stream_;
   ccx_ctx* ctx = w->ctx;
   CCX_REQUIRE(ctx, w->finalized && w->rules_set, "whisper: not finalized or rules not set");
@@ -876,7 +890,7 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
     }
     if (prompt_lens[b] > max_pl) max_pl = prompt_lens[b];
   }
-  TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, stream));
+  TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, temperature, seed, stream));
   const int total_steps = max_pl - 1 + sample_len;
   const bool use_graph = getenv("CCX_NO_GRAPH") == nullptr;
   const long ld = w->Vpad;

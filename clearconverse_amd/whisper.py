@@ -49,6 +49,7 @@ class WhisperModel:
                        "ccx_whisper_create")
         self.handle = h
         self.max_audio_seconds = float(max_audio_seconds)
+        self.sample_seed, self._sample_calls = 0, 0     # temperature > 0: Philox seed and per-call counter
         self.ctx.check(self.lib.ccx_whisper_set_max_audio(self.handle, self.max_audio_seconds), "ccx_whisper_set_max_audio")
         self._load(state_dict)
         self.set_rules(self.rules)
@@ -125,8 +126,17 @@ class WhisperModel:
         return out
 
     def decode_greedy(self, prompts: Sequence[Sequence[int]], sample_len: Optional[int] = None) -> List[dict]:
-        """Greedy DecodingTask.run over the currently encoded windows; prompts[b] are the full
-        initial tokens (sot_prev + prompt + sot)."""
+        """Greedy DecodingTask.run over the currently encoded windows (temperature 0)."""
+        return self.decode(prompts, sample_len, temperature=0.0)
+
+    def decode(self, prompts: Sequence[Sequence[int]], sample_len: Optional[int] = None, temperature: float = 0.0,
+               seed: int = 0) -> List[dict]:
+        """DecodingTask.run over the currently encoded windows; prompts[b] are the full initial tokens
+        (sot_prev + prompt + sot).  temperature 0: argmax.  temperature > 0: one Categorical(logits / T) sample per
+        step (decoding.py::GreedyDecoder.update), drawn on the device from Philox noise keyed by
+        (seed, row, step, token id) -- reproducible, not bit-equal to torch's sampler."""
+        if not (temperature >= 0.0):
+            raise _lib.CcxError("temperature must be >= 0")
         B = len(prompts)
         sample_len = sample_len or self.dims.n_text_ctx // 2
         mp = max(len(p) for p in prompts)
@@ -140,10 +150,10 @@ class WhisperModel:
         slp = np.zeros(B, dtype=np.float32)
         nsp = np.zeros(B, dtype=np.float32)
         i32p, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
-        self.ctx.check(self.lib.ccx_whisper_decode_greedy(
-            self.handle, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), mp, B, sample_len,
-            toks.ctypes.data_as(i32p), ntok.ctypes.data_as(i32p), slp.ctypes.data_as(fp), nsp.ctypes.data_as(fp),
-            _lib.current_stream_ptr()), "ccx_whisper_decode_greedy")
+        self.ctx.check(self.lib.ccx_whisper_decode(
+            self.handle, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), mp, B, sample_len, float(temperature),
+            int(seed) & 0xFFFFFFFFFFFFFFFF, toks.ctypes.data_as(i32p), ntok.ctypes.data_as(i32p), slp.ctypes.data_as(fp),
+            nsp.ctypes.data_as(fp), _lib.current_stream_ptr()), "ccx_whisper_decode")
         return [dict(tokens=toks[b, :ntok[b]].tolist(), sum_logprob=float(slp[b]),
                      avg_logprob=float(slp[b]) / (int(ntok[b]) + 1), no_speech_prob=float(nsp[b])) for b in range(B)]
 
@@ -158,10 +168,11 @@ class WhisperModel:
     def transcribe(self, audio, initial_prompt: Optional[str] = None, word_timestamps: bool = False,
                    condition_on_previous_text: bool = True, temperature: float = 0.0,
                    no_speech_threshold: Optional[float] = 0.6, logprob_threshold: Optional[float] = -1.0, **_ignored):
-        """One clip, same signature as whisper.transcribe as the reference uses it.  temperature must be
-        0 (greedy): the reference's Config.temperature = 0.1 (back/api.py:128) samples and is not
-        reproducible; parity mode is greedy.  word_timestamps only changes
-        fields the reference never reads."""
+        """One clip, same signature as whisper.transcribe as the reference uses it.  temperature 0 is the
+        parity mode (greedy); a positive float (the reference's Config.temperature = 0.1,
+        back/api.py:128) samples every token from Categorical(logits / T) -- a single temperature means no
+        fallback loop upstream either.  Draws are reproducible: seeded by `self.sample_seed` and a per-call
+        counter.  word_timestamps only changes fields the reference never reads."""
         return self.transcribe_batch([audio], [initial_prompt], condition_on_previous_text=condition_on_previous_text,
                                      temperature=temperature, no_speech_threshold=no_speech_threshold,
                                      logprob_threshold=logprob_threshold)[0]
@@ -170,8 +181,9 @@ class WhisperModel:
                          condition_on_previous_text: bool = True, temperature: float = 0.0,
                          no_speech_threshold: Optional[float] = 0.6, logprob_threshold: Optional[float] = -1.0) -> List[dict]:
         """Independent clips decoded together (each window of each clip is one sequence of a batch)."""
-        if temperature not in (0, 0.0):
-            raise _lib.CcxError("only greedy decoding (temperature=0) is implemented on the HIP path")
+        if isinstance(temperature, (tuple, list)):
+            raise _lib.CcxError("temperature fallback schedules are not implemented: pass one temperature (the reference does)")
+        temperature = float(temperature)
         n = len(audios)
         initial_prompts = list(initial_prompts) if initial_prompts is not None else [None] * n
         clips = []
@@ -203,7 +215,8 @@ class WhisperModel:
                 self.log_mel(a, [len(clips[i]) for i in grp], [state[i]["seek"] for i in grp])
                 self.encode(len(grp))
                 prompts = [self.initial_tokens(state[i]["all_tokens"][state[i]["reset"]:]) for i in grp]
-                results = self.decode_greedy(prompts)
+                self._sample_calls += 1
+                results = self.decode(prompts, temperature=temperature, seed=(int(self.sample_seed) << 32) + self._sample_calls)
                 for i, r in zip(grp, results):
                     self._advance(state[i], r, condition_on_previous_text, no_speech_threshold, logprob_threshold)
         out = []

@@ -121,6 +121,16 @@ int ccx_whisper_decode_greedy(ccx_whisper* w, const int32_t* prompt_ids, const i
                               int32_t* n_tokens_out, float* sum_logprob_out, float* no_speech_prob_out,
                               void* stream);
 
+/* DecodingTask.run with GreedyDecoder.update's temperature branch: temperature 0 = argmax (identical to
+ * ccx_whisper_decode_greedy); temperature > 0 = one sample per step from Categorical(logits / temperature) over the
+ * filtered logits -- what the reference gets from transcribe(..., temperature=self.config.temperature) with
+ * Config.temperature = 0.1 (back/api.py:128, 1286-1292).  The draw is Gumbel-max over Philox4x32-10 noise keyed by
+ * (seed, sequence row, step, vocabulary id): reproducible, independent of batch composition, but not bit-equal to
+ * torch's sampler (distributional parity).  sum_logprob uses the unscaled log-softmax, as upstream. */
+int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
+                       int sample_len, float temperature, uint64_t seed, int32_t* tokens_out, int32_t* n_tokens_out,
+                       float* sum_logprob_out, float* no_speech_prob_out, void* stream);
+
 /* ---- RE-SepFormer separator (replaces self.separator, reference back/api.py:713-717; call at
  *      back/api.py:1077 `separated = self.separator.separate_batch(subsegment)`) -------------------- */
 

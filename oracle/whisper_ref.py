@@ -341,6 +341,50 @@ class CachedDecoder:
         return (x @ m.sd["decoder.token_embedding.weight"].T).float()
 
 
+# ---------------------------------------------------------------------------------------------
+# temperature > 0 (decoding.py::GreedyDecoder.update: Categorical(logits=logits / temperature).sample()).
+# torch's sampler stream cannot be reproduced on a GPU kernel, so both sides draw by the Gumbel-max trick
+# over the SAME counter-based noise: Philox4x32-10 keyed by (seed, row, step, token id).
+# ---------------------------------------------------------------------------------------------
+def philox4x32(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """Philox4x32-10 (Salmon et al., SC'11).  ctr [..., 4] uint32, key [2] uint32 -> [..., 4] uint32."""
+    c = [ctr[..., i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & mask, p1 & mask, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & mask, p0 & mask]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def gumbel_noise(seed: int, row: int, step: int, n_vocab: int) -> np.ndarray:
+    """Standard Gumbel noise g[v] for every vocabulary id of one (row, step): the draw for id v is word v % 4 of
+    philox(counter = (v // 4, row, step, 0), key = (seed lo, seed hi)); u = (top 24 bits + 0.5) / 2^24."""
+    nq = (n_vocab + 3) // 4
+    ctr = np.zeros((nq, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nq, dtype=np.uint32)
+    ctr[:, 1] = row
+    ctr[:, 2] = step
+    x = philox4x32(ctr, np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)).reshape(-1)[:n_vocab]
+    u = ((x >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
+def sample_token(filtered_logits: torch.Tensor, temperature: float, seed: int, row: int, step: int):
+    """One GreedyDecoder.update step on already filtered logits [V]: returns (token, log-prob under the UNSCALED
+    log-softmax, Gumbel-perturbed scores) -- argmax of logits / T + g is a Categorical(logits / T) sample."""
+    lg = filtered_logits.float()
+    lp = F.log_softmax(lg, dim=-1)
+    if temperature == 0:
+        nxt = int(lg.argmax())
+        return nxt, float(lp[nxt]), lg
+    score = lg / temperature + torch.from_numpy(gumbel_noise(seed, row, step, lg.shape[-1]))
+    nxt = int(score.argmax())
+    return nxt, float(lp[nxt]), score
+
+
 def greedy_decode_cached(model: WhisperRef, xa: torch.Tensor, prompt: List[int], rules: Rules,
                          sample_len: int = 224) -> DecodeResult:
     """Greedy decode of ONE sequence with the KV cache (identical filters / bookkeeping to greedy_decode)."""

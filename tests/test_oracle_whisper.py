@@ -157,3 +157,34 @@ def test_greedy_decode_variants_agree(mini):
     assert abs(a.sum_logprob - b.sum_logprob) < 1e-3
     assert abs(a.no_speech_prob - b.no_speech_prob) < 1e-6
     assert a.tokens[0] >= r.timestamp_begin
+
+
+def test_philox_known_answer_vectors():
+    """Random123 kat_vectors for philox4x32-10: the RNG the temperature > 0 path draws from (GPU kernel and oracle)."""
+    from oracle.whisper_ref import philox4x32
+    import numpy as np
+    cases = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+             ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+             ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in cases:
+        got = philox4x32(np.array([ctr], dtype=np.uint32), np.array(key, dtype=np.uint32))[0]
+        assert tuple(int(x) for x in got) == want
+
+
+def test_gumbel_max_sampling_is_categorical():
+    """argmax(logits / T + Gumbel) over the Philox stream reproduces softmax(logits / T) frequencies."""
+    from oracle.whisper_ref import gumbel_noise, sample_token
+    import numpy as np
+    g = gumbel_noise(3, 0, 0, 51864)
+    assert abs(float(g.mean()) - 0.5772) < 0.02 and abs(float(g.std()) - 1.2825) < 0.02
+    lg = torch.tensor([1.0, 0.5, 0.0, -0.5, -1.0, float("-inf")])
+    T, N = 0.5, 20000
+    counts = np.zeros(6)
+    for step in range(N):
+        t, lp, _ = sample_token(lg, T, seed=11, row=2, step=step)
+        counts[t] += 1
+    p = torch.softmax(lg / T, -1).numpy()
+    assert counts[5] == 0
+    assert np.all(np.abs(counts / N - p) < 4 * np.sqrt(p * (1 - p) / N) + 1e-4)
+    t0, lp0, _ = sample_token(lg, 0.0, 0, 0, 0)
+    assert t0 == 0 and abs(lp0 - float(torch.log_softmax(lg, -1)[0])) < 1e-6
