@@ -16,7 +16,7 @@ from .denoise import SpectralGate
 from .pipelines import SpeakerDiarization, VoiceActivityDetection
 from .separator import SepformerSeparator
 from .speaker import ResNetEmbedder, SegmentationNet, XVectorEmbedder
-from .weights import (SepDims, WhisperDims, find_whisper_checkpoint, synthetic_pyannet_state_dict,
+from .weights import (SepDims, WhisperDims, find_sepformer_checkpoint, find_whisper_checkpoint, synthetic_pyannet_state_dict,
                       synthetic_resnet34_state_dict, synthetic_sepformer_state_dict, synthetic_whisper_state_dict,
                       synthetic_xvector_state_dict)
 from .whisper import WhisperModel
@@ -37,7 +37,8 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
     sd_ = sep_dims or SepDims()
     return {
         "whisper_dims": dict(wd.__dict__), "whisper": wsd, "whisper_source": "checkpoint" if ck is not None else f"synthetic-seed{seed}",
-        "sep_dims": dict(sd_.__dict__), "sepformer": synthetic_sepformer_state_dict(sd_, seed=seed + 1),
+        "sep_dims": dict(sd_.__dict__),
+        "sepformer": (find_sepformer_checkpoint() if sep_dims is None else None) or synthetic_sepformer_state_dict(sd_, seed=seed + 1),
         "xvector": synthetic_xvector_state_dict(seed=seed + 2),
         "pyannet_diar": synthetic_pyannet_state_dict(7, seed=seed + 3),
         "pyannet_vad": synthetic_pyannet_state_dict(3, seed=seed + 4),

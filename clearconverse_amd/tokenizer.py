@@ -101,7 +101,7 @@ class GPT2BPE:
                 n += 1
         self.b2u = dict(zip(bs, map(chr, cs)))
         self.u2b = {v: k for k, v in self.b2u.items()}
-        self.pat = re.compile(r"'s|'t|'re|'ve|'m|'ll|'d| ?[A-Za-z]+| ?\d+| ?[^\sA-Za-z\d]+|\s+(?!\S)|\s+")
+        self.pat = _gpt2_pattern()
 
     def _bpe(self, token: str) -> List[str]:
         word = list(token)
@@ -125,9 +125,64 @@ class GPT2BPE:
         return bytearray(self.u2b[c] for c in s).decode("utf-8", errors="replace")
 
 
+def _gpt2_pattern():
+    """GPT-2 pre-tokeniser (whisper/tokenizer.py pat_str).  Needs \\p classes: the `regex` module when importable,
+    else the ASCII approximation (identical on ASCII text)."""
+    try:
+        import regex
+        return regex.compile(r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+""")
+    except ImportError:
+        return re.compile(r"'s|'t|'re|'ve|'m|'ll|'d| ?[A-Za-z]+| ?\d+| ?[^\sA-Za-z\d]+|\s+(?!\S)|\s+")
+
+
+class TiktokenBPE:
+    """Byte-level BPE from a `.tiktoken` rank file -- the format openai-whisper ships its vocabulary in
+    (`whisper/assets/gpt2.tiktoken`: one `base64(token bytes) rank` pair per line).  Encoding follows tiktoken's
+    byte-pair merge: within a pre-token, repeatedly merge the adjacent pair whose concatenation has the lowest rank."""
+    name = "tiktoken-bpe"
+
+    def __init__(self, path: str):
+        import base64
+        self.ranks: dict = {}
+        with open(path, "rb") as f:
+            for line in f.read().splitlines():
+                if line.strip():
+                    tok, rank = line.split()
+                    self.ranks[base64.b64decode(tok)] = int(rank)
+        self.dec = {v: k for k, v in self.ranks.items()}
+        self.pat = _gpt2_pattern()
+
+    def _bpe(self, piece: bytes) -> List[int]:
+        parts = [piece[i:i + 1] for i in range(len(piece))]
+        while len(parts) > 1:
+            best, at = None, -1
+            for i in range(len(parts) - 1):
+                r = self.ranks.get(parts[i] + parts[i + 1])
+                if r is not None and (best is None or r < best):
+                    best, at = r, i
+            if best is None:
+                break
+            parts[at:at + 2] = [parts[at] + parts[at + 1]]
+        return [self.ranks[p] for p in parts]
+
+    def encode(self, text: str) -> List[int]:
+        ids: List[int] = []
+        for tok in self.pat.findall(text):
+            ids.extend(self._bpe(tok.encode("utf-8")))
+        return ids
+
+    def decode(self, ids: Sequence[int]) -> str:
+        return b"".join(self.dec[int(t)] for t in ids if int(t) < EOT).decode("utf-8", errors="replace")
+
+
 def get_tokenizer(cache_dir: Optional[str] = None):
+    """The vocabulary files the reference's whisper package would use, if a copy sits under MODEL_CACHE_DIR:
+    `gpt2.tiktoken` (openai-whisper's own asset) or GPT-2's `vocab.json` + `merges.txt`; else the placeholder codec."""
     cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
-    for sub in ("whisper", "gpt2", ""):
+    for sub in ("whisper", os.path.join("whisper", "assets"), "gpt2", ""):
+        t = os.path.join(cache_dir, sub, "gpt2.tiktoken")
+        if os.path.exists(t):
+            return TiktokenBPE(t)
         v, m = os.path.join(cache_dir, sub, "vocab.json"), os.path.join(cache_dir, sub, "merges.txt")
         if os.path.exists(v) and os.path.exists(m):
             return GPT2BPE(v, m)

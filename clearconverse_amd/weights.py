@@ -180,6 +180,30 @@ def synthetic_sepformer_state_dict(dims: SepDims, seed: int = 0) -> Dict[str, to
 # ----------------------------------------------------------------------------------------------
 # pyannote-style speaker networks [UPSTREAM-RECALL]: SincNet front end, XVectorSincNet, PyanNet
 # ----------------------------------------------------------------------------------------------
+def find_sepformer_checkpoint(cache_dir: Optional[str] = None) -> Optional[Dict[str, torch.Tensor]]:
+    """SpeechBrain savedir layout the reference uses (back/api.py:713-717): `<cache>/resepformer/{encoder,masknet,decoder}.ckpt`,
+    each the state_dict of that module, then the fine-tune overlay `<cache>/resepformer-ft/` the reference applies with
+    `load_state_dict(strict=False)` when all of hyperparams.yaml / masknet.ckpt / encoder.ckpt / decoder.ckpt exist
+    (back/api.py:729-746).  Returns one flat dict with `encoder.` / `masknet.` / `decoder.` prefixes, or None when the
+    base checkpoint is absent.  Files are read with weights_only=True."""
+    cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
+    base = os.path.join(cache_dir, "resepformer")
+    parts = ("encoder", "masknet", "decoder")
+    if not all(os.path.exists(os.path.join(base, f"{p}.ckpt")) for p in parts):
+        return None
+    sd: Dict[str, torch.Tensor] = {}
+    for p in parts:
+        for k, v in torch.load(os.path.join(base, f"{p}.ckpt"), map_location="cpu", weights_only=True).items():
+            sd[f"{p}.{k}"] = v.float()
+    ft = os.path.join(cache_dir, "resepformer-ft")
+    if all(os.path.exists(os.path.join(ft, f)) for f in ("hyperparams.yaml", "masknet.ckpt", "encoder.ckpt", "decoder.ckpt")):
+        for p in parts:
+            for k, v in torch.load(os.path.join(ft, f"{p}.ckpt"), map_location="cpu", weights_only=True).items():
+                if f"{p}.{k}" in sd and sd[f"{p}.{k}"].shape == v.shape:      # strict=False: unknown keys are ignored
+                    sd[f"{p}.{k}"] = v.float()
+    return sd
+
+
 def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, sample_rate: int = 16000, min_low_hz: float = 50.0,
                  min_band_hz: float = 50.0, kernel: int = 251) -> torch.Tensor:
     """Expand the learnable (low_hz_, band_hz_) of asteroid's ParamSincFB into its 40 cos + 40 sin
