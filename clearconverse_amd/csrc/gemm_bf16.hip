@@ -14,6 +14,8 @@
 // epilogue therefore writes 32 B (bf16) / 64 B (f32) contiguous per lane with no LDS
 // round trip.  For V^T destinations (EPI_HEADS, v_transposed) the un-swapped order is used
 // so each lane owns 4 consecutive ROWS of one column instead.
+#include <map>
+#include <string>
 #include "gemm_bf16.h"
 
 #define BM 128
@@ -303,7 +305,16 @@ static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream)
     // algorithmic work: 2*M*N*K flops; bytes = A + W read once + output written once
     const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;  // output element size
     const double kt = (double)p.K * (p.ntaps > 1 ? p.ntaps : 1);
-    ccx_prof_scope ps(ctx, stream, "gemm_bf16_nt_kernel", 2.0 * p.M * (double)p.N * kt,
+    // CCX_PROF_SHAPES=1: one label per (epilogue, tile, M, N, K, taps) for shape-level timing tables
+    static const bool by_shape = getenv("CCX_PROF_SHAPES") != nullptr;
+    const char* label = "gemm_bf16_nt_kernel";
+    if (by_shape && ctx->prof_on) {
+      static std::map<std::string, std::string> names;
+      char buf[160];
+      snprintf(buf, sizeof(buf), "gemm<epi%d,%dx%d> M=%d N=%d K=%d taps=%d", EPI, TBM, TBN, p.M, p.N, p.K, p.ntaps > 1 ? p.ntaps : 1);
+      label = names.emplace(buf, buf).first->second.c_str();
+    }
+    ccx_prof_scope ps(ctx, stream, label, 2.0 * p.M * (double)p.N * kt,
                       2.0 * ((double)p.M * p.K + (double)p.N * kt) + obytes * p.M * (double)p.N);
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<EPI, WM, WN, MT>), dim3(tiles), dim3(WM * WN * 64), LDS, stream, p);
   }

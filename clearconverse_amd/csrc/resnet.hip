@@ -258,6 +258,8 @@ struct ccx_resnet {
   bf16_t* act[RN_STAGES][3] = {};
   size_t act_elems[RN_STAGES] = {};
   int* mask_chunk_dev = nullptr;
+  std::vector<int> mask_host[4];   // private copies of the caller's mask_chunk arrays (ring: the copy is asynchronous)
+  int mask_slot = 0;
   int last_T = -1;
 };
 
@@ -477,8 +479,9 @@ int ccx_resnet_embed(ccx_resnet* r, const float* wav_dev, int64_t stride, int n_
     CCX_REQUIRE(ctx, mask_chunk && n_masks >= 1 && n_masks <= r->max_masks && n_w >= 1, "resnet_embed: bad mask arguments");
     for (int j = 0; j < n_masks; j++)
       CCX_REQUIRE(ctx, mask_chunk[j] >= 0 && mask_chunk[j] < n_chunks, "resnet_embed: mask_chunk[%d]=%d out of range", j, mask_chunk[j]);
-    CCX_HIP(ctx, hipMemcpyAsync(r->mask_chunk_dev, mask_chunk, (size_t)n_masks * 4, hipMemcpyHostToDevice, st));
-    CCX_HIP(ctx, hipStreamSynchronize(st));   // the host array may go away
+    std::vector<int>& keep = r->mask_host[r->mask_slot++ & 3];
+    keep.assign(mask_chunk, mask_chunk + n_masks);            // the caller's array may go away before the copy runs
+    CCX_HIP(ctx, hipMemcpyAsync(r->mask_chunk_dev, keep.data(), (size_t)n_masks * 4, hipMemcpyHostToDevice, st));
   } else {
     n_masks = n_chunks;
     CCX_REQUIRE(ctx, n_masks <= r->max_masks, "resnet_embed: %d chunks exceed the mask capacity %d", n_masks, r->max_masks);

@@ -93,44 +93,90 @@ __global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __rest
 // (optional maxpool3 over rows) + InstanceNorm over the crop's frames per channel + LeakyReLU -> bf16.
 // in: f32 rows [.., ld_in] at in_off[crop]; out: bf16 [.., ld_out] at out_off[crop], n_out[crop] frames,
 // channels >= C written as zeros.  Block = one crop, 256 threads = 64 channels x 4 frame groups.
+// (max-pool by POOL) -> InstanceNorm1d(affine) -> LeakyReLU -> bf16, in two fully parallel launches: every crop's time
+// axis is cut into INORM_CHUNKS pieces.  Launch 1 leaves (count, mean, M2) of every (crop, piece, channel); launch 2
+// combines the pieces of its crop (Chan et al. pairwise update: numerically the two-pass variance) and normalises its
+// own piece.  grid (crops, INORM_CHUNKS, channel groups of 64), 256 threads = 64 channels x 4 interleaved frame groups.
+#define INORM_CHUNKS 16
 template <int POOL>
-__global__ __launch_bounds__(256) void pool_inorm_lrelu_kernel(const float* __restrict__ in, int ld_in, const int* __restrict__ in_off,
-                                                               bf16_t* __restrict__ out, int ld_out, const int* __restrict__ out_off,
-                                                               const int* __restrict__ n_out, const float* __restrict__ g,
-                                                               const float* __restrict__ b, int C) {
-  __shared__ float red[2][4][64];
-  const int crop = blockIdx.x;
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+__device__ __forceinline__ float inorm_val(const float* __restrict__ x, int ld_in, int c, int t) {
+  if (POOL == 1) return x[(long)t * ld_in + c];
+  const float* p = x + (long)(3 * t) * ld_in + c;
+  return fmaxf(p[0], fmaxf(p[ld_in], p[2 * ld_in]));
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restrict__ in, int ld_in, const int* __restrict__ in_off,
+                                                            const int* __restrict__ n_out, float* __restrict__ part, int C, int Cpad) {
+  __shared__ float red[4][64];
+  const int crop = blockIdx.x, piece = blockIdx.y;
+  const int cl = threadIdx.x & 63, c = blockIdx.z * 64 + cl, grp = threadIdx.x >> 6;
   const int n = n_out[crop];
+  const int per = (n + INORM_CHUNKS - 1) / INORM_CHUNKS;
+  const int t0 = piece * per, t1 = min(n, t0 + per);
   const float* x = in + (long)in_off[crop] * ld_in;
   const bool live = c < C;
-  auto val = [&](int t) -> float {
-    if (POOL == 1) return x[(long)t * ld_in + c];
-    const float* p = x + (long)(3 * t) * ld_in + c;
-    return fmaxf(p[0], fmaxf(p[ld_in], p[2 * ld_in]));
-  };
   float s = 0.f;
-  if (live) for (int t = grp; t < n; t += 4) s += val(t);
-  red[0][grp][threadIdx.x & 63] = s;
+  if (live) for (int t = t0 + grp; t < t1; t += 4) s += inorm_val<POOL>(x, ld_in, c, t);
+  red[grp][cl] = s;
   __syncthreads();
-  const int cl = threadIdx.x & 63;
-  const float mean = (red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]) / (float)n;
+  const int cnt = max(t1 - t0, 0);
+  const float mean = cnt > 0 ? (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)cnt : 0.f;
+  __syncthreads();
   float q = 0.f;
-  if (live) for (int t = grp; t < n; t += 4) { const float d = val(t) - mean; q += d * d; }
-  red[1][grp][cl] = q;
+  if (live) for (int t = t0 + grp; t < t1; t += 4) { const float d = inorm_val<POOL>(x, ld_in, c, t) - mean; q += d * d; }
+  red[grp][cl] = q;
   __syncthreads();
-  const float rstd = rsqrtf((red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]) / (float)n + 1e-5f);
-  bf16_t* o = out + (long)out_off[crop] * ld_out;
-  if (c < ld_out) {
-    const float gg = live ? g[c] : 0.f, bb = live ? b[c] : 0.f;
-    for (int t = grp; t < n; t += 4) {
-      float v = 0.f;
-      if (live) {
-        v = (val(t) - mean) * rstd * gg + bb;
-        v = v >= 0.f ? v : 0.01f * v;
-      }
-      o[(long)t * ld_out + c] = f32_to_bf16(v);
+  if (grp == 0 && c < Cpad) {
+    float* o = part + (((long)crop * INORM_CHUNKS + piece) * Cpad + c) * 2;
+    o[0] = mean;
+    o[1] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  }
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ in, int ld_in, const int* __restrict__ in_off,
+                                                          bf16_t* __restrict__ out, int ld_out, const int* __restrict__ out_off,
+                                                          const int* __restrict__ n_out, const float* __restrict__ part,
+                                                          const float* __restrict__ g, const float* __restrict__ b, int C, int Cpad) {
+  const int crop = blockIdx.x, piece = blockIdx.y;
+  const int cl = threadIdx.x & 63, c = blockIdx.z * 64 + cl, grp = threadIdx.x >> 6;
+  const int n = n_out[crop];
+  const int per = (n + INORM_CHUNKS - 1) / INORM_CHUNKS;
+  const int t0 = piece * per, t1 = min(n, t0 + per);
+  if (t0 >= t1 || c >= ld_out) return;
+  const bool live = c < C;
+  // combine the pieces of this crop: mean = sum n_i mean_i / n, M2 = sum (M2_i + n_i (mean_i - mean)^2)
+  float mean = 0.f, m2 = 0.f;
+  if (live) {
+    const float* pp = part + ((long)crop * INORM_CHUNKS * Cpad + c) * 2;
+    float mi[INORM_CHUNKS], qi[INORM_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < INORM_CHUNKS; i++) { mi[i] = pp[(long)i * Cpad * 2]; qi[i] = pp[(long)i * Cpad * 2 + 1]; }
+#pragma unroll
+    for (int i = 0; i < INORM_CHUNKS; i++) {
+      const int ni = max(min(n, (i + 1) * per) - i * per, 0);
+      mean += (float)ni * mi[i];
     }
+    mean /= (float)n;
+#pragma unroll
+    for (int i = 0; i < INORM_CHUNKS; i++) {
+      const int ni = max(min(n, (i + 1) * per) - i * per, 0);
+      const float d = mi[i] - mean;
+      m2 += qi[i] + (float)ni * d * d;
+    }
+  }
+  const float rstd = rsqrtf(m2 / (float)n + 1e-5f);
+  const float* x = in + (long)in_off[crop] * ld_in;
+  bf16_t* o = out + (long)out_off[crop] * ld_out;
+  const float gg = live ? g[c] : 0.f, bb = live ? b[c] : 0.f;
+  for (int t = t0 + grp; t < t1; t += 4) {
+    float v = 0.f;
+    if (live) {
+      v = (inorm_val<POOL>(x, ld_in, c, t) - mean) * rstd * gg + bb;
+      v = v >= 0.f ? v : 0.01f * v;
+    }
+    o[(long)t * ld_out + c] = f32_to_bf16(v);
   }
 }
 
@@ -282,7 +328,7 @@ struct ccx_speaker {
   // workspaces
   long R1cap = 0;
   float2* ac = nullptr;
-  float *s1 = nullptr, *c2 = nullptr, *c3 = nullptr, *acc = nullptr, *gx = nullptr, *logit = nullptr;
+  float *s1 = nullptr, *c2 = nullptr, *c3 = nullptr, *acc = nullptr, *gx = nullptr, *logit = nullptr, *inorm_part = nullptr;
   bf16_t *s1n = nullptr, *s2n = nullptr, *s3n = nullptr, *a1 = nullptr, *a2 = nullptr, *a5 = nullptr, *pooled = nullptr, *hA = nullptr, *hB = nullptr;
   long* crop_off = nullptr; long* w_off = nullptr; int* w_len = nullptr;
   int *crop_len = nullptr, *off1 = nullptr, *off2 = nullptr, *off3 = nullptr, *nF1 = nullptr, *nF2 = nullptr, *nF3 = nullptr, *nFv = nullptr;
@@ -419,21 +465,27 @@ int run_sincnet(ccx_speaker* s, const float* wav, const Plan& P, hipStream_t st)
                        s->nF1, s->ac, n.filt_t, n.filt_sum, s->s1);
   }
   CCX_CHECK_LAUNCH(ctx);
-  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<1>, dim3(P.n, 2), dim3(256), 0, st, s->s1, 80, s->off1, s->s1n, 80, s->off1, s->nF1,
-                     n.n0g, n.n0b, 80);
+  hipLaunchKernelGGL(inorm_partial_kernel<1>, dim3(P.n, INORM_CHUNKS, 2), dim3(256), 0, st, s->s1, 80, s->off1, s->nF1, s->inorm_part, 80, 128);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(inorm_apply_kernel<1>, dim3(P.n, INORM_CHUNKS, 2), dim3(256), 0, st, s->s1, 80, s->off1, s->s1n, 80, s->off1, s->nF1,
+                     s->inorm_part, n.n0g, n.n0b, 80, 128);
   CCX_CHECK_LAUNCH(ctx);
   GemmParams p;
   memset(&p, 0, sizeof(p));   // conv1d(80 -> 60, k5) as a GEMM over a strided view: row m = frames m..m+4
   p.A = s->s1n; p.lda = 80; p.W = n.W1; p.ldw = 448; p.M = (int)P.R1; p.N = 60; p.K = 448; p.bias = n.b1; p.out = s->c2; p.ldo = 128;
   PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
-  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<3>, dim3(P.n, 1), dim3(256), 0, st, s->c2, 128, s->off1, s->s2n, 64, s->off2, s->nF2,
-                     n.n1g, n.n1b, 60);
+  hipLaunchKernelGGL(inorm_partial_kernel<3>, dim3(P.n, INORM_CHUNKS, 1), dim3(256), 0, st, s->c2, 128, s->off1, s->nF2, s->inorm_part, 60, 128);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(inorm_apply_kernel<3>, dim3(P.n, INORM_CHUNKS, 1), dim3(256), 0, st, s->c2, 128, s->off1, s->s2n, 64, s->off2, s->nF2,
+                     s->inorm_part, n.n1g, n.n1b, 60, 128);
   CCX_CHECK_LAUNCH(ctx);
   memset(&p, 0, sizeof(p));   // conv1d(60 -> 60, k5), channels padded to 64
   p.A = s->s2n; p.lda = 64; p.W = n.W2; p.ldw = 320; p.M = (int)P.R2; p.N = 60; p.K = 320; p.bias = n.b2; p.out = s->c3; p.ldo = 128;
   PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
-  hipLaunchKernelGGL(pool_inorm_lrelu_kernel<3>, dim3(P.n, 1), dim3(256), 0, st, s->c3, 128, s->off2, s->s3n, 64, s->off3, s->nF3,
-                     n.n2g, n.n2b, 60);
+  hipLaunchKernelGGL(inorm_partial_kernel<3>, dim3(P.n, INORM_CHUNKS, 1), dim3(256), 0, st, s->c3, 128, s->off2, s->nF3, s->inorm_part, 60, 128);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(inorm_apply_kernel<3>, dim3(P.n, INORM_CHUNKS, 1), dim3(256), 0, st, s->c3, 128, s->off2, s->s3n, 64, s->off3, s->nF3,
+                     s->inorm_part, n.n2g, n.n2b, 60, 128);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }
@@ -522,6 +574,7 @@ int ccx_speaker_finalize(ccx_speaker* s) {
   const size_t R1 = (size_t)s->R1cap + 16, R2 = R1 / 3 + 16, R3 = R2 / 3 + 16, C = (size_t)s->max_crops;
   PTRY(palloc(s, &s->ac, C)); PTRY(palloc(s, &s->s1, R1 * 80)); PTRY(palloc(s, &s->s1n, R1 * 80 + 1024));
   PTRY(palloc(s, &s->c2, R1 * 128)); PTRY(palloc(s, &s->s2n, R2 * 64 + 1024)); PTRY(palloc(s, &s->c3, R2 * 128)); PTRY(palloc(s, &s->s3n, R3 * 64 + 1024));
+  PTRY(palloc(s, &s->inorm_part, (size_t)C * INORM_CHUNKS * 128 * 2));
   PTRY(palloc(s, &s->crop_off, C)); PTRY(palloc(s, &s->crop_len, C)); PTRY(palloc(s, &s->w_off, C)); PTRY(palloc(s, &s->w_len, C));
   PTRY(palloc(s, &s->off1, C)); PTRY(palloc(s, &s->off2, C)); PTRY(palloc(s, &s->off3, C));
   PTRY(palloc(s, &s->nF1, C)); PTRY(palloc(s, &s->nF2, C)); PTRY(palloc(s, &s->nF3, C)); PTRY(palloc(s, &s->nFv, C));

@@ -60,12 +60,14 @@ class Annotation:
         return len(self._tracks)
 
 
-def load_mono_16k(path_or_wave) -> np.ndarray:
+def load_mono_16k(path_or_wave):
     """The pipelines read the file themselves (raw, NOT denoised -- SURVEY.md section 3b)."""
     if isinstance(path_or_wave, dict):
         w = path_or_wave["waveform"]
-        x = w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)
         sr = int(path_or_wave.get("sample_rate", SR))
+        if torch.is_tensor(w) and w.is_cuda and sr == SR and w.dtype == torch.float32 and (w.dim() == 1 or w.shape[0] == 1):
+            return w.reshape(-1)            # already resident: the windows are cut on the device, no host round trip
+        x = w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)
     else:
         x, sr = read_wav(str(path_or_wave))
     x = np.asarray(x, dtype=np.float32)
@@ -160,7 +162,10 @@ class VoiceActivityDetection:
         return starts, crops
 
     def _score(self, outs, starts, n):
-        if self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
+        if len({o.shape for o in outs}) == 1:
+            outs = np.stack(outs)               # equal windows: one vectorised reduction for all of them
+            sc = 1.0 - np.exp(outs[..., :1]) if self.net.powerset else outs.max(axis=-1, keepdims=True)
+        elif self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
             sc = [1.0 - np.exp(o[:, :1]) for o in outs]
         else:
             sc = [o.max(axis=-1, keepdims=True) for o in outs]
@@ -255,7 +260,7 @@ class SpeakerDiarization:
                 plans.append(None)
                 continue
             starts = sliding_chunks(len(x), self.win, self.step)
-            dev = torch.from_numpy(x).to(self.net.device)
+            dev = x.to(self.net.device) if torch.is_tensor(x) else torch.from_numpy(x).to(self.net.device)
             cr = []
             for s in starts:
                 c = dev[s:s + self.win]
@@ -273,19 +278,22 @@ class SpeakerDiarization:
                 per_item.append(None)
                 continue
             starts, i0, n = pl
-            multi = [powerset_to_multilabel(o) if self.net.powerset else (o > 0.5).astype(np.float32) for o in seg[i0:i0 + n]]
+            arr = np.stack(seg[i0:i0 + n])                                   # [windows, frames, classes]: windows are equal-sized
+            multi_all = powerset_to_multilabel(arr) if self.net.powerset else (arr > 0.5).astype(np.float32)
+            multi = list(multi_all)
+            act = multi_all > 0                                              # [windows, frames, speakers]
+            alone = multi_all.sum(axis=-1) == 1
+            clean = act & alone[..., None]
+            n_act, n_clean = act.sum(axis=1), clean.sum(axis=1)
+            keep = act.mean(axis=1) >= self.min_active                       # local speakers active for >= min_active_ratio
+            use_clean = n_clean >= 0.5 * n_act                               # prefer overlap-free frames when enough remain
             keys = []
-            for ci, m in enumerate(multi):
-                alone = (m.sum(axis=-1) == 1)
-                for sp in range(m.shape[1]):
-                    act = m[:, sp] > 0
-                    if act.mean() < self.min_active:
-                        continue
-                    clean = act & alone
-                    w = clean if clean.sum() >= 0.5 * act.sum() else act
-                    keys.append((ci, sp))
-                    e_crops.append(i0 + ci)
-                    e_weights.append(torch.from_numpy(w.astype(np.float32)))
+            for ci, sp in zip(*np.nonzero(keep)):                            # row-major: window, then speaker
+                ci, sp = int(ci), int(sp)
+                w = clean[ci, :, sp] if use_clean[ci, sp] else act[ci, :, sp]
+                keys.append((ci, sp))
+                e_crops.append(i0 + ci)
+                e_weights.append(torch.from_numpy(w.astype(np.float32)))
             per_item.append((starts, multi, keys))
         if not e_crops:
             embs = np.zeros((0, getattr(self.emb, "DIM", 512)), dtype=np.float32)

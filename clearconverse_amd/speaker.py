@@ -201,9 +201,10 @@ class SegmentationNet(_SpeakerNet):
         self.powerset = bool(powerset)
 
     def segment_numpy(self, crops: Sequence) -> List[np.ndarray]:
-        """Like segment_batch but returns host arrays with ONE device->host copy per launch group."""
-        res: List[np.ndarray] = []
+        """Like segment_batch but returns host arrays.  All launch groups are queued first; the device->host copies
+        (one per group) follow, so the GPU never waits for the host to pack the next group."""
         i64p, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int)
+        pending = []
         for i0, i1 in self._groups(crops):
             part = crops[i0:i1]
             buf, offs, lens = self._pack(part)
@@ -213,6 +214,9 @@ class SegmentationNet(_SpeakerNet):
             self.ctx.check(self.lib.ccx_speaker_segment(self.handle, buf.data_ptr(), offs.ctypes.data_as(i64p), lens.ctypes.data_as(ip),
                                                         len(part), out.data_ptr(), cap, frames.ctypes.data_as(ip), _lib.current_stream_ptr()),
                            "ccx_speaker_segment")
+            pending.append((out, frames, buf))          # buf stays referenced until its kernels have run
+        res: List[np.ndarray] = []
+        for out, frames, _ in pending:
             host = out[: int(frames.sum())].cpu().numpy()
             r = 0
             for f in frames:
