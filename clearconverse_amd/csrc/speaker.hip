@@ -59,33 +59,46 @@ __global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __rest
                                                              const float* __restrict__ filt_t,   // [251][80]
                                                              const float* __restrict__ filt_sum, // [80]
                                                              float* __restrict__ out) {
-  __shared__ float xs[96 * SN_STRIDE + SN_K + 3];
-  const int crop = blockIdx.y, p0 = blockIdx.x * 32;
+  // 64 pooled frames (192 conv positions) per block; a thread owns 4 filters x 12 positions, so one tap costs it
+  // 12 LDS reads + one float4 of weights for 48 FMAs (the 1 x 24 blocking was LDS-issue-bound: 25 loads per 24 FMAs)
+  __shared__ float xs[192 * SN_STRIDE + SN_K + 5];
+  const int crop = blockIdx.y, p0 = blockIdx.x * 64;
   const int np = n_pool[crop];
   if (p0 >= np) return;
   const float* x = wav + crop_off[crop];
   const int n = crop_len[crop];
   const int s0 = p0 * 3 * SN_STRIDE;
-  for (int i = threadIdx.x; i < 96 * SN_STRIDE + SN_K; i += 320) xs[i] = (s0 + i < n) ? x[s0 + i] : 0.f;
+  for (int i = threadIdx.x; i < 192 * SN_STRIDE + SN_K; i += 320) xs[i] = (s0 + i < n) ? x[s0 + i] : 0.f;
   __syncthreads();
-  const int f = threadIdx.x % SN_F, grp = threadIdx.x / SN_F;   // grp 0..3 -> pooled frames p0 + 8*grp .. +8
-  float acc[24];
+  const int f4 = threadIdx.x % 20, grp = threadIdx.x / 20;   // filters 4*f4..+3; pooled frames p0 + 4*grp .. +3
+  float acc[4][12];
 #pragma unroll
-  for (int j = 0; j < 24; j++) acc[j] = 0.f;
-  const float* xb = xs + grp * 24 * SN_STRIDE;
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 12; j++) acc[i][j] = 0.f;
+  const float* xb = xs + grp * 12 * SN_STRIDE;
   for (int k = 0; k < SN_K; k++) {
-    const float w = filt_t[k * SN_F + f];
+    const float4 w = *(const float4*)(filt_t + k * SN_F + 4 * f4);
 #pragma unroll
-    for (int j = 0; j < 24; j++) acc[j] = fmaf(w, xb[j * SN_STRIDE + k], acc[j]);
+    for (int j = 0; j < 12; j++) {
+      const float xv = xb[j * SN_STRIDE + k];
+      acc[0][j] = fmaf(w.x, xv, acc[0][j]); acc[1][j] = fmaf(w.y, xv, acc[1][j]);
+      acc[2][j] = fmaf(w.z, xv, acc[2][j]); acc[3][j] = fmaf(w.w, xv, acc[3][j]);
+    }
   }
   const float2 a_c = ac[crop];
-  const float cs = a_c.y * filt_sum[f];
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int p = p0 + 8 * grp + j;
+  for (int j = 0; j < 4; j++) {
+    const int p = p0 + 4 * grp + j;
     if (p < np) {
-      const float v0 = fabsf(a_c.x * acc[3 * j] + cs), v1 = fabsf(a_c.x * acc[3 * j + 1] + cs), v2 = fabsf(a_c.x * acc[3 * j + 2] + cs);
-      out[((long)row_off[crop] + p) * SN_F + f] = fmaxf(v0, fmaxf(v1, v2));
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float cs = a_c.y * filt_sum[4 * f4 + i];
+        const float v0 = fabsf(a_c.x * acc[i][3 * j] + cs), v1 = fabsf(a_c.x * acc[i][3 * j + 1] + cs), v2 = fabsf(a_c.x * acc[i][3 * j + 2] + cs);
+        o[i] = fmaxf(v0, fmaxf(v1, v2));
+      }
+      *(float4*)(out + ((long)row_off[crop] + p) * SN_F + 4 * f4) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
@@ -257,15 +270,16 @@ __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __rest
       a0 = fmaf(w[4 * k], h4.x, a0); a1 = fmaf(w[4 * k + 1], h4.y, a1);
       a2 = fmaf(w[4 * k + 2], h4.z, a2); a3 = fmaf(w[4 * k + 3], h4.w, a3);
     }
-    gate[j] = g0 + (a0 + a1) + (a2 + a3);
+    // every thread applies its own gate non-linearity (rows 0..127 i, 128..255 f, 256..383 g, 384..511 o), so the
+    // serial part after the barrier is one tanh per cell.  tanh(x) = 1 - 2 / (exp(2x) + 1): ~1e-7 abs in fp32.
+    const float pre = g0 + (a0 + a1) + (a2 + a3);
+    const bool is_g = (j >> 7) == 2;
+    const float ex = __expf(is_g ? 2.f * pre : -pre);
+    gate[j] = is_g ? 1.f - 2.f / (ex + 1.f) : 1.f / (1.f + ex);
     __syncthreads();
     if (j < 128) {
-      const float ig = 1.f / (1.f + __expf(-gate[j]));
-      const float fg = 1.f / (1.f + __expf(-gate[128 + j]));
-      const float gg = tanhf(gate[256 + j]);
-      const float og = 1.f / (1.f + __expf(-gate[384 + j]));
-      c = fg * c + ig * gg;
-      const float h = og * tanhf(c);
+      c = gate[128 + j] * c + gate[j] * gate[256 + j];
+      const float h = gate[384 + j] * (1.f - 2.f / (__expf(2.f * c) + 1.f));
       hs[j] = h;
       hout[(r0 + t) * 256 + dir * 128 + j] = f32_to_bf16(h);
     }
@@ -461,7 +475,7 @@ int run_sincnet(ccx_speaker* s, const float* wav, const Plan& P, hipStream_t st)
   for (int i = 0; i < P.n; i++) maxp = P.f1[i] > maxp ? P.f1[i] : maxp;
   {
     ccx_prof_scope ps(ctx, st, "sinc_conv_pool_kernel", 0.0, 0.0);
-    hipLaunchKernelGGL(sinc_conv_pool_kernel, dim3(ccx_cdiv(maxp, 32), P.n), dim3(320), 0, st, wav, s->crop_off, s->crop_len, s->off1,
+    hipLaunchKernelGGL(sinc_conv_pool_kernel, dim3(ccx_cdiv(maxp, 64), P.n), dim3(320), 0, st, wav, s->crop_off, s->crop_len, s->off1,
                        s->nF1, s->ac, n.filt_t, n.filt_sum, s->s1);
   }
   CCX_CHECK_LAUNCH(ctx);
