@@ -248,11 +248,12 @@ __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __rest
   const int crop = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
   const int n = n_rows[crop];
   const long r0 = row_off[crop];
-  float w[128];
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 w[64];   // this thread's W_hh row as 64 pairs: the dot product below compiles to v_pk_fma_f32 (2 FMAs per lane and issue)
   {
     const float4* wp = (const float4*)(whh + ((long)dir * 512 + j) * 128);
 #pragma unroll
-    for (int k = 0; k < 32; k++) { const float4 v = wp[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    for (int k = 0; k < 32; k++) { const float4 v = wp[k]; w[2 * k] = (f2){v.x, v.y}; w[2 * k + 1] = (f2){v.z, v.w}; }
   }
   if (j < 128) hs[j] = 0.f;
   float c = 0.f;
@@ -263,16 +264,18 @@ __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __rest
     const float g0 = gnext;
     const int tn = dir == 0 ? t + 1 : t - 1;
     if (step + 1 < n) gnext = gx[(r0 + tn) * 1024 + dir * 512 + j];   // prefetch, independent of h
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 32; k++) {
       const float4 h4 = ((const float4*)hs)[k];
-      a0 = fmaf(w[4 * k], h4.x, a0); a1 = fmaf(w[4 * k + 1], h4.y, a1);
-      a2 = fmaf(w[4 * k + 2], h4.z, a2); a3 = fmaf(w[4 * k + 3], h4.w, a3);
+      // the compiler splits a 2-vector fma into two v_fmac_f32; the packed form issues both in one VALU slot
+      const f2 h01 = (f2){h4.x, h4.y}, h23 = (f2){h4.z, h4.w};
+      asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(w[2 * k]), "v"(h01));
+      asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(w[2 * k + 1]), "v"(h23));
     }
     // every thread applies its own gate non-linearity (rows 0..127 i, 128..255 f, 256..383 g, 384..511 o), so the
     // serial part after the barrier is one tanh per cell.  tanh(x) = 1 - 2 / (exp(2x) + 1): ~1e-7 abs in fp32.
-    const float pre = g0 + (a0 + a1) + (a2 + a3);
+    const float pre = g0 + (a0.x + a0.y) + (a1.x + a1.y);
     const bool is_g = (j >> 7) == 2;
     const float ex = __expf(is_g ? 2.f * pre : -pre);
     gate[j] = is_g ? 1.f - 2.f / (ex + 1.f) : 1.f / (1.f + ex);
