@@ -63,6 +63,7 @@ struct DecSelectParams {
   // device memory (so that a captured step graph serves every temperature / seed); row0 = batch row of sequence 0 of
   // this launch (lanes), so that the noise of a sequence does not depend on how the batch is split
   const unsigned* sample_cfg; int row0;
+  int sample;   // 0: greedy kernel (sample_cfg ignored); 1: kernel with the temperature > 0 branch
 };
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,

@@ -656,6 +656,9 @@ __device__ __forceinline__ float gumbel_from_u32(unsigned x) {
 }
 
 #define SEL_V4 13
+// SAMPLE = false is the greedy kernel (no noise code, no extra registers: the sampling branch costs the 1024-thread
+// block its register budget and spills); SAMPLE = true adds the temperature > 0 draw.
+template <bool SAMPLE>
 __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   __shared__ float sh[16];
   __shared__ float sh_v[16];
@@ -799,9 +802,9 @@ __global__ __launch_bounds__(1024) void dec_select_kernel(DecSelectParams p) {
   const float lse = force_ts ? lse_ts : mx_all + logf(se_text + se_ts);   // log-normaliser of the re-filtered logits
 
   // ---- temperature > 0: Categorical(logits / T) by the Gumbel-max trick (argmax of logits / T + Gumbel noise) ----
-  const float temperature = __uint_as_float(p.sample_cfg[0]);
+  const float temperature = SAMPLE ? __uint_as_float(p.sample_cfg[0]) : 0.f;
   int samp = -1; float samp_logit = 0.f;
-  if (temperature > 0.f) {
+  if (SAMPLE && temperature > 0.f) {
     const uint2 key = make_uint2(p.sample_cfg[1], p.sample_cfg[2]);
     const float inv_t = 1.0f / temperature;
     float best = -INFINITY, best_logit = -INFINITY; int best_i = 0x7fffffff;
@@ -876,7 +879,8 @@ int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_em
 }
 
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(dec_select_kernel, dim3(B), dim3(1024), 0, stream, p);
+  if (p.sample) hipLaunchKernelGGL(dec_select_kernel<true>, dim3(B), dim3(1024), 0, stream, p);
+  else hipLaunchKernelGGL(dec_select_kernel<false>, dim3(B), dim3(1024), 0, stream, p);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
 }

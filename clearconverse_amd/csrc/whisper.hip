@@ -102,6 +102,7 @@ struct ccx_whisper {
   float *dx = nullptr, *dx2 = nullptr, *pend = nullptr, *dq = nullptr, *dlogits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   bf16_t *dattn = nullptr, *dffn = nullptr, *dxn = nullptr;
   int *cur_tok = nullptr, *pos = nullptr, *prompt = nullptr, *gen = nullptr, *n_done = nullptr;
+  bool sampling = false;            // temperature > 0 in the current decode call (selects the kernel variant)
   unsigned* sample_cfg = nullptr;   // {temperature bits, seed lo, seed hi, 0}: read by the select kernel every step
   DecSeqState* state = nullptr;
   int max_prompt_cap = 0, sample_cap = 0;
@@ -804,7 +805,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
     sp.max_initial_ts = w->rules.max_initial_timestamp_index;
     sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx + ro * D; sp.D = D;
-    sp.sample_cfg = w->sample_cfg; sp.row0 = b0;
+    sp.sample_cfg = w->sample_cfg; sp.row0 = b0; sp.sample = w->sampling ? 1 : 0;
     TRY(ccx_launch_dec_select(ctx, sp, B, stream));
   }
   return CCX_OK;
@@ -825,6 +826,7 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
   CCX_HIP(w->ctx, hipMemcpyAsync(w->pos, ps.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->prompt, prompt_ids, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, 16, stream));
+  w->sampling = temperature > 0.f;
   unsigned cfg[4] = {0u, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), 0u};
   memcpy(&cfg[0], &temperature, 4);
   CCX_HIP(w->ctx, hipMemcpyAsync(w->sample_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, stream));
@@ -941,7 +943,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   if (use_graph && total_steps > 1) {
     for (int i = 0; i < nl; i++) {
       // graphs are specific to (lane rows, sample_len, max_prompt)
-      const long key = (((long)lanes[i].b0 * 4099 + lanes[i].B) * 4099 + sample_len) * 4099 + max_prompt;
+      const long key = ((((long)lanes[i].b0 * 4099 + lanes[i].B) * 4099 + sample_len) * 4099 + max_prompt) * 2 + (w->sampling ? 1 : 0);
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;
