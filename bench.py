@@ -256,8 +256,12 @@ def main():
                             frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=pmc.get("hbm_bytes_per_launch"), launches=cnt_,
                             avg_launch_us=round(ms * 1e3 / cnt_, 2), flops_per_launch=fl / cnt_, measured=where)
             ach = by / (ms * 1e-3) / 1e9
+            traffic = pmc.get("hbm_bytes_per_launch")
+            if traffic is not None and "sequences_per_launch" in pmc:
+                # the counter passes decode the group in one lane (192 sequences per launch): scale to this run's launches
+                traffic = traffic / pmc["sequences_per_launch"] * (by / cnt_) / (dims.n_audio_ctx * dims.n_text_state * 2 * 2)
             return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=pmc.get("hbm_bytes_per_launch"), launches=cnt_,
+                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic, launches=cnt_,
                         avg_launch_us=round(ms * 1e3 / cnt_, 2), bytes_per_launch=by / cnt_, measured=where)
 
         agg = aggregate_records(recs)

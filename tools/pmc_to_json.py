@@ -1,0 +1,55 @@
+"""rocprofv3 counter_collection CSVs (one FETCH_SIZE pass, one WRITE_SIZE pass) -> per-kernel HBM bytes per launch.
+FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM /
+rocprofv3 section); WRITE_SIZE is exact; both are in KB."""
+import csv, json, sys, collections
+
+def load(path, counter):
+    per = collections.defaultdict(lambda: [0, 0.0])
+    seen = set()
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            for pre in ("void ", "(anonymous namespace)::"):
+                name = name.replace(pre, "")
+            name = name.split("(")[0]
+            key = (r["Dispatch_Id"], name)
+            a = per[name]
+            if key not in seen:
+                seen.add(key); a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return per
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --sample-len 4` "
+        "(pipeline workload, 32 clips, 192-sequence decode group in 3 lanes of 64); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+        "(gfx950 reports half of wide coalesced reads); KB units")
+for name in sorted(set(fetch) | set(write)):
+    n = max(fetch.get(name, [0, 0])[0], write.get(name, [0, 0])[0])
+    if n == 0:
+        continue
+    fk = fetch.get(name, [0, 0.0])[1] / n
+    wk = write.get(name, [0, 0.0])[1] / n
+    out[name] = {"launches": n, "FETCH_SIZE_kb_per_launch": fk, "WRITE_SIZE_kb_per_launch": wk,
+                 "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "note": note}
+# aggregates over template instantiations (bench.py labels the GEMM family by its base name)
+base = collections.defaultdict(lambda: [0, 0.0, 0.0])
+for name, v in out.items():
+    if "<" in name:
+        b = base[name.split("<")[0]]
+        b[0] += v["launches"]; b[1] += v["FETCH_SIZE_kb_per_launch"] * v["launches"]; b[2] += v["WRITE_SIZE_kb_per_launch"] * v["launches"]
+for name, (n, fk, wk) in base.items():
+    if name not in out:
+        out[name] = {"launches": n, "FETCH_SIZE_kb_per_launch": fk / n, "WRITE_SIZE_kb_per_launch": wk / n,
+                     "hbm_bytes_per_launch": (2.0 * fk + wk) / n * 1024.0, "note": note + "; all template instantiations together"}
+# Counter collection serialises dispatches, so the decode-lane stream probe finds no concurrent stream and the whole
+# 192-sequence group is decoded in ONE lane: the cross-attention launches of these passes cover 192 sequences.
+for name in out:
+    if name.startswith("dec_attention_kernel"):
+        out[name]["sequences_per_launch"] = 192
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
+for k, v in top:
+    print(f"{k[:60]:60s} launches {v['launches']:6d}  HBM MB/launch {v['hbm_bytes_per_launch'] / 1e6:10.2f}")
