@@ -514,8 +514,13 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
     for (int it = 0; it < 8; it++) {
       int key = base + it * 8 + g;
       key = key < kend ? key : kend - 1;
-      kf[it] = *(const bf16x8*)(Kb + (long)key * 64);
-      vf[it] = *(const bf16x8*)(Vb + (long)key * 64);
+      if (FINAL) {   // self attention: the cache rows were written moments ago, keep them cacheable
+        kf[it] = *(const bf16x8*)(Kb + (long)key * 64);
+        vf[it] = *(const bf16x8*)(Vb + (long)key * 64);
+      } else {       // cross attention: 0.9 GB per layer and step, read exactly once -> non-temporal
+        kf[it] = __builtin_nontemporal_load((const bf16x8*)(Kb + (long)key * 64));
+        vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vb + (long)key * 64));
+      }
     }
     float s[8];
 #pragma unroll
