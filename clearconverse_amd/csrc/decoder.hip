@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   int nks = kz1 - ks0;
   nks = nks < 0 ? 0 : (nks > per_w ? per_w : nks);
 
+  // bias of this thread's output column (the epilogue walks e = tid + 256 i, and 256 % BN == 0): loaded up front so
+  // that the epilogue has no dependent memory round trip of its own
+  float bias_v = 0.f;
+  {
+    const int nb_ = n0 + tid % BN;
+    if (p.bias && blockIdx.z == 0 && nb_ < p.N) bias_v = p.bias[nb_];
+  }
+
   // ---------------- 1. weight (and bf16 activation) prefetch ----------------
   // W is stored fragment-packed (whisper.hip pack_mfma_rows): tile (n/16, k/32) holds the 64 lanes'
   // 16-byte A fragments back to back, so one wave load is 1 KB contiguous and successive k-steps
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; w++) v += red[(((w * NT + i) * MT + j) * 64 + ln) * 4 + rg];
-    if (p.bias && blockIdx.z == 0) v += p.bias[n];
+    v += bias_v;
     if (EPI == DEPI_BF16_GELU) {
       ((bf16_t*)p.out)[(long)m * p.ldo + n] = f32_to_bf16(gelu_erf(v));
     } else if (EPI == DEPI_PARTIAL) {
@@ -303,7 +311,14 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   const int nv = K >> 2;
-  float4 v[4];
+  float4 v[4], gg[4], bb[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {   // affine parameters first: no dependent load after the reductions
+    const int idx = lane + 64 * i;
+    const int ic = idx < nv ? idx : 0;
+    gg[i] = ((const float4*)g)[ic];
+    bb[i] = ((const float4*)b)[ic];
+  }
   float sm = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -335,10 +350,9 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
   for (int i = 0; i < 4; i++) {
     const int idx = lane + 64 * i;
     if (idx < nv) {
-      const float4 gg = ((const float4*)g)[idx], bb = ((const float4*)b)[idx];
       uint2 o;
-      o.x = pack_bf16x2((v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y);
-      o.y = pack_bf16x2((v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w);
+      o.x = pack_bf16x2((v[i].x - mean) * rstd * gg[i].x + bb[i].x, (v[i].y - mean) * rstd * gg[i].y + bb[i].y);
+      o.y = pack_bf16x2((v[i].z - mean) * rstd * gg[i].z + bb[i].z, (v[i].w - mean) * rstd * gg[i].w + bb[i].w);
       ((uint2*)(out + (long)m * K))[idx] = o;
     }
   }
