@@ -84,6 +84,17 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     if (p.bias && blockIdx.z == 0 && nb_ < p.N) bias_v = p.bias[nb_];
   }
 
+  // DEPI_SELF_QKV appends k/v at pos[row]: the rows this thread stores (e = tid + 256 i -> row e / BN) are known now
+  constexpr int EPI_ITERS = (BN * MROWS + 255) / 256;
+  int pos_v[EPI_ITERS];
+  if (EPI == DEPI_SELF_QKV) {
+#pragma unroll
+    for (int i = 0; i < EPI_ITERS; i++) {
+      const int m_ = m0 + (tid + 256 * i) / BN;
+      pos_v[i] = p.pos[m_ < p.M ? m_ : p.M - 1];
+    }
+  }
+
   // ---------------- 1. weight (and bf16 activation) prefetch ----------------
   // W is stored fragment-packed (whisper.hip pack_mfma_rows): tile (n/16, k/32) holds the 64 lanes'
   // 16-byte A fragments back to back, so one wave load is 1 KB contiguous and successive k-steps
@@ -270,7 +281,10 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     for (int j = 0; j < MT; j++) *(f32x4*)(red + (((wave * NT + i) * MT + j) * 64 + lane) * 4) = acc[i][j];
   __syncthreads();
 
-  for (int e = tid; e < BN * MROWS; e += 256) {
+#pragma unroll
+  for (int it = 0; it < EPI_ITERS; it++) {
+    const int e = tid + 256 * it;
+    if (e >= BN * MROWS) break;
     const int nl = e % BN, r = e / BN;
     const int n = n0 + nl, m = m0 + r;
     if (n >= p.N || m >= p.M) continue;
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         const int hh = nn >> 6, d = nn & 63;
         const int H = D >> 6;
         bf16_t* cache = which ? p.cache_v : p.cache_k;
-        cache[(((long)m * H + hh) * p.cache_T + p.pos[m]) * 64 + d] = f32_to_bf16(v);
+        cache[(((long)m * H + hh) * p.cache_T + pos_v[it]) * 64 + d] = f32_to_bf16(v);
       }
     }
   }
