@@ -122,11 +122,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with WORLD_SIZE={args.gpus} (got {world})")
+    if os.environ.get("CCX_BENCH_SHARE_GPU"):
+        local_rank = 0      # rehearsal of the N > 1 code path on a one-GPU box (with CCX_BENCH_BACKEND=gloo): all ranks on cuda:0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CCX_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from clearconverse_amd import _lib
     from clearconverse_amd.audio import synthetic_clip

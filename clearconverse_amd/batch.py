@@ -177,7 +177,7 @@ def broadcast_weights(state_dicts: Optional[dict], src: int = 0, device="cpu") -
     """The start-of-job collective (C1): rank `src` holds the weights of every model
     (models.build_state_dicts); all tensors are packed into ONE byte blob and sent with ONE broadcast (RCCL: a direct
     1 -> N-1 send over the xGMI links), the small manifest (names / shapes / dtypes / non-tensor entries) as an object
-    broadcast before it.  Returns the same nested dict on every rank (tensors are views of the received blob)."""
+    broadcast before it.  Returns the same nested dict on every rank (host tensors: views of one host copy of the received blob)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         if state_dicts is None:
@@ -215,10 +215,11 @@ def broadcast_weights(state_dicts: Optional[dict], src: int = 0, device="cpu") -
         blob = torch.empty(manifest["total"], dtype=torch.uint8, device=device)
     if manifest["total"]:
         dist.broadcast(blob, src=src)
+    host = blob.cpu()        # state dicts are host objects everywhere else (loaders repack them before the upload)
     out: dict = dict(manifest["plain"])
     for model, key, shape, dtype, o, nbytes, plain in manifest["tensors"]:
         d = out.setdefault(model, {})
-        d[key] = plain if shape is None else blob[o:o + nbytes].view(getattr(torch, dtype)).reshape(shape)
+        d[key] = plain if shape is None else host[o:o + nbytes].view(getattr(torch, dtype)).reshape(shape)
     return out
 
 

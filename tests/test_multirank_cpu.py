@@ -62,6 +62,7 @@ def _bcast_worker(rank, world, port, q):
                "net_a": {"w": torch.randn(5, 3, generator=g), "b": torch.randn(7, generator=g).to(torch.float16), "powerset": 1},
                "net_b": {"idx": torch.arange(11, dtype=torch.int64), "z": torch.randn(2, 2, 2, generator=g)}}
     got = broadcast_weights(sds, src=0, device="cpu")
+    assert all(v.device.type == "cpu" for d in got.values() if isinstance(d, dict) for v in d.values() if torch.is_tensor(v))
     q.put((rank, {m: ({k: (v.tolist(), str(v.dtype)) if torch.is_tensor(v) else v for k, v in d.items()} if isinstance(d, dict) else d)
                   for m, d in got.items()}))
     dist.destroy_process_group()
