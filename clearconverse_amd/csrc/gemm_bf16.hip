@@ -332,8 +332,9 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   if (EPI == EPI_HEADS) fits = fits && p.N % 256 == 0 && p.d_model % 256 == 0;
   const bool big = fits && (forced == 256 || (forced != 128 && big_tiles >= 224));
   if (big) return launch_epi_geo<EPI, 2, 4, 8>(ctx, p, stream);
-  // narrow layers (ResNet 32/64 channels): 128 x 64 tiles, 2 waves, so that at most half a tile is idle
-  if (EPI != EPI_HEADS && p.N <= 64 && forced == 0) return launch_epi_geo<EPI, 2, 1, 4>(ctx, p, stream);
+  // narrow layers (ResNet 32/64 channels, SincNet 60): 256 x 64 tiles, 4 waves of 64 rows (80 KB LDS, 2 blocks per CU).
+  // Measured over the ResNet-34 convolutions: 128 x 64 / 2 waves 59.6 ms per step, 128 x 64 / 4 waves 51.6, 256 x 64 49.9.
+  if (EPI != EPI_HEADS && p.N <= 64 && forced == 0) return launch_epi_geo<EPI, 4, 1, 4>(ctx, p, stream);
   return launch_epi_geo<EPI, 2, 2, 4>(ctx, p, stream);
 }
 
