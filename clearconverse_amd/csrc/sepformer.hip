@@ -83,6 +83,34 @@ __global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __rest
   const int n_qt = (len + 15) >> 4, n_kt = n_qt;
   const bf16_t* base = qkv + (long)s0 * 384 + head * 16;
 
+  // K and V fragments of this (sequence, head).  Sequences of up to 160 tokens (every intra-chunk call: 150) keep them in
+  // registers for all query tiles; the 2-byte V gathers then run once per sequence instead of once per query tile.
+  auto load_k = [&](int kt) -> bf16x4v {
+    int krow = kt * 16 + l15;
+    krow = krow < len ? krow : len - 1;
+    return *(const bf16x4v*)(base + 128 + (long)krow * 384 + 4 * h4);   // A operand: K[key l15][d = 4*h4 + j]
+  };
+  auto load_v = [&](int kt) -> bf16x4v {
+    bf16x4v v;                                                           // B operand of O = P V: V[key = 4*h4 + j][d = l15]
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int vr = kt * 16 + 4 * h4 + j;
+      vr = vr < len ? vr : len - 1;
+      v[j] = (short)base[256 + (long)vr * 384 + l15];
+    }
+    return v;
+  };
+  const bool resident = n_kt <= 10;
+  bf16x4v k_all[10], v_all[10];
+  if (resident) {
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+      const int kt = t < n_kt ? t : n_kt - 1;
+      k_all[t] = load_k(kt);
+      v_all[t] = load_v(kt);
+    }
+  }
+
   for (int qt = 0; qt < n_qt; qt++) {
     // B operand of S^T = K * Q^T:  B[k = d = 4*h4 + j][col = query l15]
     int qrow = qt * 16 + l15;
@@ -97,21 +125,9 @@ __global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __rest
 #pragma unroll
       for (int t = 0; t < 10; t++) {
         if (t < nk) {
-          const int kt = kt0 + t;
-          int krow = kt * 16 + l15;
-          krow = krow < len ? krow : len - 1;
-          // A operand: K[key l15][d = 4*h4 + j]
-          const bf16x4v kf = *(const bf16x4v*)(base + 128 + (long)krow * 384 + 4 * h4);
+          const bf16x4v kf = resident ? k_all[t] : load_k(kt0 + t);
           s[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          // B operand of O = P V:  V[key = 4*h4 + j][d = l15]
-          bf16x4v v;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            int vr = kt * 16 + 4 * h4 + j;
-            vr = vr < len ? vr : len - 1;
-            v[j] = (short)base[256 + (long)vr * 384 + l15];
-          }
-          vf[t] = v;
+          vf[t] = resident ? v_all[t] : load_v(kt0 + t);
         }
       }
       // s[t][r] = score(query l15, key kt*16 + 4*h4 + r)
