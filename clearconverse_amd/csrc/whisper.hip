@@ -114,7 +114,7 @@ struct ccx_whisper {
   hipEvent_t own_event = nullptr;
   // decode lanes: disjoint row ranges of one batch stepping concurrently on their own streams, staggered so
   // that one lane's HBM-bound cross attention overlaps the other lanes' latency-bound linears.  The gain is
-  // modest (4 % at 192 sequences): the small kernels slow down 3-5x while HBM is saturated by another lane.
+  // modest (3-4 % at 192 sequences): the small kernels slow down 3-5x while HBM is saturated by another lane.
   static constexpr int kMaxLanes = 4;
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
@@ -915,7 +915,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     const char* e = getenv("CCX_DEC_LANES");
     const int forced = e ? atoi(e) : 0;
     if (forced >= 1) nl = forced;
-    else nl = B >= 144 ? 3 : (B >= 96 ? 2 : 1);   // measured at 192 sequences: 1 lane 316.8, 2 306.6, 3 303.0, 4 301.7 ms
+    else nl = B >= 144 ? 3 : (B >= 96 ? 2 : 1);   // measured at 192 sequences x 65 steps: 1 lane 292.5, 2 286.8, 3 284.9, 4 284.8 ms
     if (nl > ccx_whisper::kMaxLanes) nl = ccx_whisper::kMaxLanes;
     while (nl > 1 && B / nl < 16) nl--;
   }
