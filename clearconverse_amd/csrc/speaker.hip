@@ -323,6 +323,13 @@ struct SincNetW {
   bf16_t *W1, *W2;  // conv k5: [60][448] (5 x 80 padded) and [60][320] (5 x 64)
 };
 
+struct Plan {
+  int n = 0;
+  long R1 = 0, R2 = 0, R3 = 0;
+  std::vector<long> coff;
+  std::vector<int> clen, off1, off2, off3, f1, f2, f3, fv;
+};
+
 }  // namespace
 
 struct ccx_speaker {
@@ -347,6 +354,9 @@ struct ccx_speaker {
   float2* ac = nullptr;
   float *s1 = nullptr, *c2 = nullptr, *c3 = nullptr, *acc = nullptr, *gx = nullptr, *logit = nullptr, *inorm_part = nullptr;
   bf16_t *s1n = nullptr, *s2n = nullptr, *s3n = nullptr, *a1 = nullptr, *a2 = nullptr, *a5 = nullptr, *pooled = nullptr, *hA = nullptr, *hB = nullptr;
+  // host copies of the per-call tables: the uploads are asynchronous, so the last few calls' tables stay alive here
+  Plan plan_ring[4];
+  int plan_slot = 0;
   long* crop_off = nullptr; long* w_off = nullptr; int* w_len = nullptr;
   int *crop_len = nullptr, *off1 = nullptr, *off2 = nullptr, *off3 = nullptr, *nF1 = nullptr, *nF2 = nullptr, *nF3 = nullptr, *nFv = nullptr;
 };
@@ -431,13 +441,6 @@ int load_sincnet(ccx_speaker* s, const std::string& pre) {
   return CCX_OK;
 }
 
-struct Plan {
-  int n = 0;
-  long R1 = 0, R2 = 0, R3 = 0;
-  std::vector<long> coff;
-  std::vector<int> clen, off1, off2, off3, f1, f2, f3, fv;
-};
-
 int make_plan(ccx_speaker* s, const int* n_samples, const int64_t* offsets, int n, Plan& P) {
   ccx_ctx* ctx = s->ctx;
   P.n = n;
@@ -464,8 +467,7 @@ int upload_plan(ccx_speaker* s, const Plan& P, hipStream_t st) {
   UPI(s->crop_off, P.coff); UPI(s->crop_len, P.clen); UPI(s->off1, P.off1); UPI(s->off2, P.off2); UPI(s->off3, P.off3);
   UPI(s->nF1, P.f1); UPI(s->nF2, P.f2); UPI(s->nF3, P.f3); UPI(s->nFv, P.fv);
 #undef UPI
-  CCX_HIP(ctx, hipStreamSynchronize(st));
-  return CCX_OK;
+  return CCX_OK;   // no sync: P lives in the handle's ring, and the device tables are rewritten in stream order
 }
 
 // SincNet over all crops: leaves s3n [R3][64] bf16 (60 channels + zero pad)
@@ -613,7 +615,8 @@ int ccx_speaker_embed(ccx_speaker* s, const float* wav, const int64_t* offsets, 
   ccx_ctx* ctx = s->ctx;
   hipStream_t st = (hipStream_t)stream_;
   CCX_REQUIRE(ctx, s->finalized && s->kind == 0 && wav && offsets && n_samples && out && n >= 1 && n <= s->max_crops, "speaker_embed: bad arguments (n=%d, max %d)", n, s->max_crops);
-  Plan P;
+  Plan& P = s->plan_ring[s->plan_slot++ & 3];
+  P = Plan();
   PTRY(make_plan(s, n_samples, offsets, n, P));
   PTRY(upload_plan(s, P, st));
   PTRY(run_sincnet(s, wav, P, st));
@@ -675,7 +678,8 @@ int ccx_speaker_segment(ccx_speaker* s, const float* wav, const int64_t* offsets
   ccx_ctx* ctx = s->ctx;
   hipStream_t st = (hipStream_t)stream_;
   CCX_REQUIRE(ctx, s->finalized && s->kind == 1 && wav && offsets && n_samples && out && frames_out && n >= 1 && n <= s->max_crops, "speaker_segment: bad arguments");
-  Plan P;
+  Plan& P = s->plan_ring[s->plan_slot++ & 3];
+  P = Plan();
   PTRY(make_plan(s, n_samples, offsets, n, P));
   CCX_REQUIRE(ctx, P.R3 <= out_capacity_rows, "speaker_segment: output needs %ld rows, capacity %ld", P.R3, (long)out_capacity_rows);
   for (int i = 0; i < n; i++) frames_out[i] = P.f3[i];

@@ -20,6 +20,6 @@ for name in ("vad_pipeline", "diarization"):
     torch.cuda.synchronize()
     pr.disable()
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(18)
     print("=====", name)
     print("\n".join(l for l in s.getvalue().splitlines() if l.strip())[:4500])
