@@ -63,6 +63,23 @@ def test_ten_second_chunk_and_geometry_change(net):
     assert _rel(got2[0], R.resnet_embed(sd, short)[0]) < TOL
 
 
+def test_chunk_results_do_not_depend_on_batch_mates(net):
+    """Size-independent property at the pipeline's chunk size (10 s): an embedding is bit-identical whatever else is in
+    the launch (GEMM tiles straddle chunk boundaries, but every output element sees only its own chunk)."""
+    sd, emb = net
+    waves = np.stack([_clip(40 + i, 160000) for i in range(6)])
+    t = torch.from_numpy(waves)
+    a = emb.embed_chunks(t).cpu()
+    b = emb.embed_chunks(t.flip(0)).cpu().flip(0)
+    assert torch.equal(a, b)
+    c = torch.cat([emb.embed_chunks(t[i:i + 1]).cpu() for i in range(6)])
+    assert torch.equal(a, c)
+    # masks: all-ones weights equal the unweighted statistics up to the 1e-8 regulariser of the weighted formula
+    w = torch.ones(6, 589)
+    d = emb.embed_chunks(t, w, list(range(6))).cpu()
+    assert float((a - d).abs().max()) < 1e-3 * float(a.abs().max())
+
+
 def test_capacity_and_argument_errors(net):
     from clearconverse_amd import _lib
     _, emb = net
