@@ -172,6 +172,110 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ fe
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stage-1 convolution (32 -> 32 channels, 3x3, stride 1) as a direct MFMA kernel.  Through the GEMM these six layers are
+// the slowest of the network: N = 32 leaves half a tile idle, a tap is padded 96 -> 128 and every pixel is DMA-ed into
+// LDS twelve times.  Here a block stages its (4 + 2) x (64 + 2) pixel halo tile ONCE (96-byte pixel pitch: the
+// ds_read_b128 fragment reads are conflict-free, tools/lds_bank_sim.py), every wave keeps all 9 x 32 x 32 weights in 72
+// VGPRs, and one output row of 64 pixels is 72 v_mfma_f32_16x16x32_bf16 (K = the 32 input channels of one tap).
+// Operands are swapped (M = output channels, permuted so that a lane ends up with 8 consecutive channels of one pixel:
+// one 16-byte store), folded-BatchNorm bias, optional residual, ReLU in registers.
+// ------------------------------------------------------------------------------------------------------------
+template <bool HAS_RESID>
+__global__ __launch_bounds__(256) void conv3x3_c32_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk,   // [32][3][128]
+                                                          const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                          bf16_t* __restrict__ out, int H, int W) {
+  constexpr int TW = 64, TH = 4, PITCH = 96;                       // bytes per staged pixel (64 used)
+  __shared__ __attribute__((aligned(16))) char tile[(TH + 2) * (TW + 2) * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, hq = lane >> 4;
+  const long Wp = W + 2;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, img = blockIdx.z;
+  const bf16_t* src = in + ((long)img * (H + 2) + y0) * Wp * 32;
+  // ---- stage the halo tile: 6 rows x 66 pixels x 4 chunks of 16 B; all loads are issued before the first LDS store ----
+  constexpr int NCH = (TH + 2) * (TW + 2) * 4, NIT = (NCH + 255) / 256;
+  uint4 stg[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int idx = tid + 256 * it;
+    const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
+    const int px = rem >> 2, q = rem & 3;
+    stg[it] = make_uint4(0, 0, 0, 0);
+    if (idx < NCH && x0 + px < Wp) stg[it] = *(const uint4*)(src + ((long)row * Wp + x0 + px) * 32 + q * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int idx = tid + 256 * it;
+    const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
+    const int px = rem >> 2, q = rem & 3;
+    if (idx < NCH) *(uint4*)(tile + (row * (TW + 2) + px) * PITCH + q * 16) = stg[it];
+  }
+  // ---- weights: A operand of tap t, channel block j: row i = l15 -> output channel 8 (i >> 2) + 4 j + (i & 3) ----
+  bf16x8 wf[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int co = 8 * (l15 >> 2) + 4 * j + (l15 & 3);
+      wf[t][j] = *(const bf16x8*)(wpk + (long)co * 384 + (t / 3) * 128 + (t % 3) * 32 + hq * 8);
+    }
+  float bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) bv[i] = bias[8 * hq + i];
+  // residual of this lane's four pixels: fetched now, used in the epilogue (no dependent load after the MFMAs)
+  const long orow = ((long)img * (H + 2) + y0 + wave + 1) * Wp + 1;
+  uint4 rres[4];
+  if (HAS_RESID) {
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      const int x = x0 + pt * 16 + l15;
+      rres[pt] = make_uint4(0, 0, 0, 0);
+      if (x < W) rres[pt] = *(const uint4*)(resid + (orow + x) * 32 + 8 * hq);
+    }
+  }
+  __syncthreads();
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[pt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    const int kh = t / 3, kw = t % 3;
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++) {
+      // B operand: column = pixel pt*16 + l15, k-slice hq: 8 input channels of the tap's pixel
+      const bf16x8 bfrag = *(const bf16x8*)(tile + ((wave + kh) * (TW + 2) + pt * 16 + l15 + kw) * PITCH + hq * 16);
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], bfrag, acc[pt][j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: lane (pixel l15, quarter hq) holds output channels 8 hq + 4 j + r ----
+#pragma unroll
+  for (int pt = 0; pt < 4; pt++) {
+    const int x = x0 + pt * 16 + l15;
+    if (x >= W) continue;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[4 * j + r] = acc[pt][j][r] + bv[4 * j + r];
+    const long off = (orow + x) * 32 + 8 * hq;
+    if (HAS_RESID) {
+      const uint32_t rw[4] = {rres[pt].x, rres[pt].y, rres[pt].z, rres[pt].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        v[2 * i] += __uint_as_float(rw[i] << 16);
+        v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+      }
+    }
+    uint4 o;
+    o.x = pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)); o.y = pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+    o.z = pack_bf16x2(fmaxf(v[4], 0.f), fmaxf(v[5], 0.f)); o.w = pack_bf16x2(fmaxf(v[6], 0.f), fmaxf(v[7], 0.f));
+    *(uint4*)(out + off) = o;
+  }
+}
+
 // Weighted statistics pooling (pyannote StatsPool / wespeaker TSTP) over the W4 frames of the last stage.
 // grid (10, n_masks), 256 threads = channels.  pooled [mask][5120]: mean at c*10 + h, std at 2560 + c*10 + h.
 __global__ __launch_bounds__(256) void tstp_kernel(const bf16_t* __restrict__ act, int W4, const int* __restrict__ mask_chunk,
@@ -335,6 +439,18 @@ void stage_dims(int T, StageDims (&d)[RN_STAGES]) {
 // one convolution as a GEMM over a strided view of `in` (stage si) writing the padded layout of `out` (stage so)
 int run_conv(ccx_resnet* r, const Conv& cv, int epi, const bf16_t* in, const StageDims& di, bf16_t* out, const StageDims& dn,
              const bf16_t* resid, int n_chunks, hipStream_t st) {
+  static const bool direct = getenv("CCX_RESNET_DIRECT") == nullptr || atoi(getenv("CCX_RESNET_DIRECT")) != 0;
+  if (direct && cv.cin == 32 && cv.cout == 32 && cv.k == 3 && cv.stride == 1 && di.H % 4 == 0 && (epi == EPI_BF16_RELU || epi == EPI_BF16_ADD_RELU)) {
+    const dim3 grid(ccx_cdiv(di.W, 64), di.H / 4, n_chunks);
+    {
+      ccx_prof_scope ps(r->ctx, st, "conv3x3_c32_kernel", 2.0 * 9 * 32 * 32 * (double)n_chunks * di.H * di.W,
+                        (double)n_chunks * di.H * di.W * 64.0 * (resid ? 3 : 2));
+      if (resid) hipLaunchKernelGGL(conv3x3_c32_kernel<true>, grid, dim3(256), 0, st, in, cv.W, cv.b, resid, out, di.H, di.W);
+      else hipLaunchKernelGGL(conv3x3_c32_kernel<false>, grid, dim3(256), 0, st, in, cv.W, cv.b, resid, out, di.H, di.W);
+    }
+    CCX_CHECK_LAUNCH(r->ctx);
+    return CCX_OK;
+  }
   GemmParams p;
   memset(&p, 0, sizeof(p));
   const int s = cv.stride;
