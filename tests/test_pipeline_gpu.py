@@ -40,12 +40,13 @@ def test_vad_and_diarization_return_annotations(models, tmp_path):
     assert len(a) == len(b) and all(abs(x[0] - y[0]) < 0.02 and abs(x[1] - y[1]) < 0.02 for x, y in zip(a, b))   # 16-bit WAV quantisation
 
 
-def test_processor_run_on_wav_file(models, tmp_path):
+@pytest.mark.parametrize("temperature", [0.0, 0.1])      # 0.1 = the reference's Config default (back/api.py:128)
+def test_processor_run_on_wav_file(models, tmp_path, temperature):
     from clearconverse_amd.processor import Config, EnhancedAudioProcessor
     clip = synthetic_clip(1, 30.0)[: 16000 * 10]
     path = str(tmp_path / "ten.wav")
     write_wav(path, clip)
-    p = EnhancedAudioProcessor(Config(temperature=0.0), load_models_immediately=False, model_loader=lambda cfg, dev: models)
+    p = EnhancedAudioProcessor(Config(temperature=temperature), load_models_immediately=False, model_loader=lambda cfg, dev: models)
     seen = []
     out = p.run(path, output_dir=str(tmp_path / "out"), progress_callback=lambda pct, msg: seen.append(pct))
     assert seen[:1] == [5] and 30 in seen
