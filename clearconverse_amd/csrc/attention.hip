@@ -98,22 +98,22 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
       }
     }
     // reg r of sub-tile kt <-> key t*64 + kt*32 + 16*(r>>3) + 8*hh + (r&7)
+    // softmax in the exp2 domain with the scale folded into ONE fma per score: p = exp2(s * c - m * c), c = scale * log2(e).
+    // (The kernel is VALU-bound at d = 64: every issue slot saved per score is MFMA time regained.)  m_run is kept scaled.
     float mx = -1e30f;
     const bool tail = (t * 64 + 64 > S);
 #pragma unroll
     for (int kt = 0; kt < 2; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float v = sT[kt][r] * scale_log2e;
         if (tail) {
           const int key = t * 64 + kt * 32 + 16 * (r >> 3) + 8 * hh + (r & 7);
-          if (key >= S) v = -INFINITY;
+          if (key >= S) sT[kt][r] = -INFINITY;
         }
-        sT[kt][r] = v;
-        mx = fmaxf(mx, v);
+        mx = fmaxf(mx, sT[kt][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * scale_log2e);      // scale > 0: the maximum commutes with it
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
     for (int kt = 0; kt < 2; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float pv = __builtin_amdgcn_exp2f(sT[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kt][r], scale_log2e, -m_new));   // -inf stays -inf -> 0
         sT[kt][r] = pv;
         psum += pv;
       }
