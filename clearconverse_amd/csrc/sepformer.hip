@@ -15,6 +15,7 @@
 #include "../../include/ccx.h"
 #include "ccx_common.h"
 #include "elementwise.h"
+#include <type_traits>
 #include "gemm_bf16.h"
 
 namespace {
@@ -118,42 +119,46 @@ __global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __rest
     const bf16x4v qf = *(const bf16x4v*)(base + (long)qrow * 384 + 4 * h4);
     float m_run = -1e30f, l_run = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};  // O tile: col = d (l15), rows = query 4*h4 + r
-    for (int kt0 = 0; kt0 < n_kt; kt0 += 10) {
-      const int nk = (n_kt - kt0) < 10 ? (n_kt - kt0) : 10;
+    // one block of up to 10 key tiles; FULL (exactly 10: every intra-chunk call) drops the per-tile branches, which
+    // otherwise make up most of the instruction stream of this VALU-bound kernel
+    auto key_block = [&](int kt0, int nk, auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
       f32x4 s[10];
       bf16x4v vf[10];
 #pragma unroll
       for (int t = 0; t < 10; t++) {
-        if (t < nk) {
+        if (FULL || t < nk) {
           const bf16x4v kf = resident ? k_all[t] : load_k(kt0 + t);
           s[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           vf[t] = resident ? v_all[t] : load_v(kt0 + t);
         }
       }
-      // s[t][r] = score(query l15, key kt*16 + 4*h4 + r)
-      float mx = m_run;
+      // s[t][r] = score(query l15, key kt*16 + 4*h4 + r).  The kernel is VALU-bound (16-wide heads): keys past `len` can
+      // only sit in the last key tile, and the scale is folded into the one fma in front of exp2 (m_run is kept scaled).
+      float mx = -1e30f;
 #pragma unroll
       for (int t = 0; t < 10; t++)
-        if (t < nk) {
+        if (FULL || t < nk) {
+          if ((kt0 + t) * 16 + 16 > len) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int key = (kt0 + t) * 16 + 4 * h4 + r;
-            const float v = key < len ? s[t][r] * scale_log2e : -INFINITY;
-            s[t][r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 4; r++)
+              if ((kt0 + t) * 16 + 4 * h4 + r >= len) s[t][r] = -INFINITY;
           }
+#pragma unroll
+          for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[t][r]);
         }
       mx = fmaxf(mx, lane_xor16(mx));
       mx = fmaxf(mx, lane_xor32(mx));
+      mx = fmaxf(m_run, mx * scale_log2e);
       const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
       m_run = mx;
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 10; t++)
-        if (t < nk) {
+        if (FULL || t < nk) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float pv = __builtin_amdgcn_exp2f(s[t][r] - mx);
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[t][r], scale_log2e, -mx));
             s[t][r] = pv;
             ps += pv;
           }
@@ -167,12 +172,17 @@ __global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __rest
       for (int r = 0; r < 4; r++) o[r] *= arow[r];
 #pragma unroll
       for (int t = 0; t < 10; t++)
-        if (t < nk) {
+        if (FULL || t < nk) {
           union { bf16x4v v; uint32_t u[2]; } pa;  // A operand: P[query l15][key 4*h4 + j]
           pa.u[0] = pack_bf16x2(s[t][0], s[t][1]);
           pa.u[1] = pack_bf16x2(s[t][2], s[t][3]);
           o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa.v, vf[t], o, 0, 0, 0);
         }
+    };
+    for (int kt0 = 0; kt0 < n_kt; kt0 += 10) {
+      const int nk = (n_kt - kt0) < 10 ? (n_kt - kt0) : 10;
+      if (nk == 10) key_block(kt0, 10, std::true_type{});
+      else key_block(kt0, nk, std::false_type{});
     }
     float lt = l_run + lane_xor16(l_run);
     lt += lane_xor32(lt);
