@@ -460,6 +460,14 @@ static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ks
 template <int NT, int ACT, int EPI>
 static int launch_dec_linear_mt(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
   const int M = p.M;
+  // prefetch depth = k-steps per wave: 6 covers K = 768 (24 k-steps over 4 waves) without the two clamped duplicate
+  // loads per fragment row and the 25 % idle registers of the depth-8 instantiation, which K = 1024 slices need
+  const int need = ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), 4);
+  if (need <= 6) {
+    if (M <= 16) return launch_dec_linear_inst<1, NT, 6, ACT, EPI>(ctx, p, ksplit, stream);
+    if (M <= 32) return launch_dec_linear_inst<2, NT, 6, ACT, EPI>(ctx, p, ksplit, stream);
+    return launch_dec_linear_inst<4, NT, 6, ACT, EPI>(ctx, p, ksplit, stream);
+  }
   if (M <= 16) return launch_dec_linear_inst<1, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
   if (M <= 32) return launch_dec_linear_inst<2, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
   return launch_dec_linear_inst<4, NT, 8, ACT, EPI>(ctx, p, ksplit, stream);
