@@ -171,8 +171,9 @@ class VoiceActivityDetection:
             sc = [o.max(axis=-1, keepdims=True) for o in outs]
         return aggregate(sc, starts, n, self.win)[:, 0]
 
-    def batch(self, items: Sequence) -> List[Annotation]:
-        """Several files / waveforms at once: all windows of all items go through the network together."""
+    def begin(self, items: Sequence):
+        """Cut the windows of all items and QUEUE the network; returns a handle for `finish`.  Nothing waits for the GPU
+        here, so a caller can queue more work (e.g. the diarization network) before collecting."""
         xs = [load_mono_16k(it) for it in items]
         plans, crops = [], []
         for x in xs:
@@ -182,7 +183,11 @@ class VoiceActivityDetection:
             starts, cr = self._chunks(x)
             plans.append((starts, len(crops), len(cr)))
             crops += cr
-        outs = self.net.segment_numpy(crops) if crops else []
+        return xs, plans, (self.net.segment_launch(crops) if crops else [])
+
+    def finish(self, handle) -> List[Annotation]:
+        xs, plans, pending = handle
+        outs = self.net.segment_fetch(pending)
         anns = []
         for x, pl in zip(xs, plans):
             if pl is None:
@@ -195,6 +200,10 @@ class VoiceActivityDetection:
             dur = len(x) / SR
             anns.append(Annotation([(max(0.0, s), min(dur, e), "SPEECH") for s, e in regions if min(dur, e) > max(0.0, s)]))
         return anns
+
+    def batch(self, items: Sequence) -> List[Annotation]:
+        """Several files / waveforms at once: all windows of all items go through the network together."""
+        return self.finish(self.begin(items))
 
     def __call__(self, path_or_wave) -> Annotation:
         return self.batch([path_or_wave])[0]
@@ -251,8 +260,13 @@ class SpeakerDiarization:
               num_speakers: Optional[int] = None) -> List[Annotation]:
         """Several files / waveforms at once: segmentation windows and speaker-embedding crops of all items
         are batched through the networks; clustering / reconstruction stay per item."""
-        lo = num_speakers or min_speakers or 1
-        hi = num_speakers or max_speakers or 20
+        return self.finish(self.embed(self.begin(items)), min_speakers, max_speakers, num_speakers)
+
+    # The three stages of `batch`, separately callable so that a driver can keep the GPU busy while the host works:
+    # begin  -- cut windows, QUEUE the segmentation network (no wait);
+    # embed  -- fetch the frame scores, pick the local speakers' pooling masks on the host, QUEUE the embedding network;
+    # finish -- fetch the embeddings, cluster and rebuild the timelines on the host.
+    def begin(self, items: Sequence):
         xs = [load_mono_16k(it) for it in items]
         plans, crops = [], []
         for x in xs:
@@ -269,7 +283,11 @@ class SpeakerDiarization:
                 cr.append(c)
             plans.append((starts, len(crops), len(cr)))
             crops += cr
-        seg = self.net.segment_numpy(crops) if crops else []
+        return xs, plans, crops, (self.net.segment_launch(crops) if crops else [])
+
+    def embed(self, handle):
+        xs, plans, crops, pending = handle
+        seg = self.net.segment_fetch(pending)
         # local speakers of every window of every item
         per_item = []
         e_crops, e_weights = [], []
@@ -296,15 +314,22 @@ class SpeakerDiarization:
                 e_weights.append(torch.from_numpy(w.astype(np.float32)))
             per_item.append((starts, multi, keys))
         if not e_crops:
-            embs = np.zeros((0, getattr(self.emb, "DIM", 512)), dtype=np.float32)
+            embs = None
         elif hasattr(self.emb, "embed_chunks"):
             # chunk-level embedder (WeSpeaker ResNet-34): the trunk runs once per window, pooling once per local speaker
             used = sorted(set(e_crops))
             where = {g: k for k, g in enumerate(used)}
-            embs = self.emb.embed_chunks(torch.stack([crops[g] for g in used]), torch.stack(e_weights),
-                                         [where[g] for g in e_crops]).cpu().numpy()
+            embs = self.emb.embed_chunks(torch.stack([crops[g] for g in used]), torch.stack(e_weights), [where[g] for g in e_crops])
         else:
-            embs = self.emb.embed_batch([crops[g] for g in e_crops], weights=e_weights).cpu().numpy()
+            embs = self.emb.embed_batch([crops[g] for g in e_crops], weights=e_weights)
+        return xs, per_item, embs                                            # embs: device tensor, still being computed
+
+    def finish(self, handle, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
+               num_speakers: Optional[int] = None) -> List[Annotation]:
+        lo = num_speakers or min_speakers or 1
+        hi = num_speakers or max_speakers or 20
+        xs, per_item, embs = handle
+        embs = np.zeros((0, getattr(self.emb, "DIM", 512)), dtype=np.float32) if embs is None else embs.cpu().numpy()
         anns, e0 = [], 0
         for x, it in zip(xs, per_item):
             if it is None or not it[2]:

@@ -200,9 +200,8 @@ class SegmentationNet(_SpeakerNet):
         self.n_classes = n_classes
         self.powerset = bool(powerset)
 
-    def segment_numpy(self, crops: Sequence) -> List[np.ndarray]:
-        """Like segment_batch but returns host arrays.  All launch groups are queued first; the device->host copies
-        (one per group) follow, so the GPU never waits for the host to pack the next group."""
+    def segment_launch(self, crops: Sequence) -> list:
+        """Queue the network over all launch groups of `crops`; nothing is copied back yet (see segment_fetch)."""
         i64p, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int)
         pending = []
         for i0, i1 in self._groups(crops):
@@ -215,6 +214,11 @@ class SegmentationNet(_SpeakerNet):
                                                         len(part), out.data_ptr(), cap, frames.ctypes.data_as(ip), _lib.current_stream_ptr()),
                            "ccx_speaker_segment")
             pending.append((out, frames, buf))          # buf stays referenced until its kernels have run
+        return pending
+
+    @staticmethod
+    def segment_fetch(pending: list) -> List[np.ndarray]:
+        """Device->host copies (one per launch group) of a segment_launch: per-crop [frames, classes] host arrays."""
         res: List[np.ndarray] = []
         for out, frames, _ in pending:
             host = out[: int(frames.sum())].cpu().numpy()
@@ -223,6 +227,11 @@ class SegmentationNet(_SpeakerNet):
                 res.append(host[r:r + int(f)])
                 r += int(f)
         return res
+
+    def segment_numpy(self, crops: Sequence) -> List[np.ndarray]:
+        """Like segment_batch but returns host arrays.  All launch groups are queued first; the device->host copies
+        (one per group) follow, so the GPU never waits for the host to pack the next group."""
+        return self.segment_fetch(self.segment_launch(crops))
 
     def segment_batch(self, crops: Sequence) -> List[torch.Tensor]:
         outs: List[torch.Tensor] = []
