@@ -17,8 +17,9 @@ from recollection of the published sources [UPSTREAM-RECALL]:
     weights; the convolutional trunk only sees the chunk waveform, so it is the same for the speakers
     of one chunk.
 
-PARITY STATUS: **parity unpinned** (no fixture in the reference, no independent implementation in
-this image).
+PARITY STATUS: **parity unpinned** (no fixture in the reference).  The Kaldi fbank is cross-checked against the
+independently written kaldi mode of `transformers.audio_utils.spectrogram` (tests/test_oracle_wespeaker.py); the
+ResNet-34 itself has no second implementation in this image.
 """
 from __future__ import annotations
 
