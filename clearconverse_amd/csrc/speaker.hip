@@ -71,19 +71,26 @@ __global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __rest
   for (int i = threadIdx.x; i < 192 * SN_STRIDE + SN_K; i += 320) xs[i] = (s0 + i < n) ? x[s0 + i] : 0.f;
   __syncthreads();
   const int f4 = threadIdx.x % 20, grp = threadIdx.x / 20;   // filters 4*f4..+3; pooled frames p0 + 4*grp .. +3
-  float acc[4][12];
+  // accumulators as pairs of adjacent FILTERS (acc[i2][j] = filters 4 f4 + 2 i2, +1 at position j): w.xy / w.zw are
+  // register pairs already, the sample is broadcast, so every update is one v_pk_fma_f32 (2 FMAs per issue slot)
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 acc[2][12];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 12; j++) acc[i][j] = 0.f;
+    for (int j = 0; j < 12; j++) acc[i][j] = (f2){0.f, 0.f};
   const float* xb = xs + grp * 12 * SN_STRIDE;
   for (int k = 0; k < SN_K; k++) {
     const float4 w = *(const float4*)(filt_t + k * SN_F + 4 * f4);
+    const f2 w01 = (f2){w.x, w.y}, w23 = (f2){w.z, w.w};
 #pragma unroll
     for (int j = 0; j < 12; j++) {
-      const float xv = xb[j * SN_STRIDE + k];
-      acc[0][j] = fmaf(w.x, xv, acc[0][j]); acc[1][j] = fmaf(w.y, xv, acc[1][j]);
-      acc[2][j] = fmaf(w.z, xv, acc[2][j]); acc[3][j] = fmaf(w.w, xv, acc[3][j]);
+      // op_sel_hi:[1,0,1]: the high lane of the packed op reads the LOW half of the sample operand (broadcast); the
+      // compiler emits only half of these updates as v_pk_fma_f32 on its own
+      f2 xx;
+      xx.x = xb[j * SN_STRIDE + k];
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[0][j]) : "v"(w01), "v"(xx));
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[1][j]) : "v"(w23), "v"(xx));
     }
   }
   const float2 a_c = ac[crop];
@@ -95,7 +102,8 @@ __global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const float cs = a_c.y * filt_sum[4 * f4 + i];
-        const float v0 = fabsf(a_c.x * acc[i][3 * j] + cs), v1 = fabsf(a_c.x * acc[i][3 * j + 1] + cs), v2 = fabsf(a_c.x * acc[i][3 * j + 2] + cs);
+        const float v0 = fabsf(a_c.x * acc[i >> 1][3 * j][i & 1] + cs), v1 = fabsf(a_c.x * acc[i >> 1][3 * j + 1][i & 1] + cs),
+                    v2 = fabsf(a_c.x * acc[i >> 1][3 * j + 2][i & 1] + cs);
         o[i] = fmaxf(v0, fmaxf(v1, v2));
       }
       *(float4*)(out + ((long)row_off[crop] + p) * SN_F + 4 * f4) = make_float4(o[0], o[1], o[2], o[3]);
