@@ -74,6 +74,28 @@ def test_full_depth_model(ccx_ctx):
         m.close()
 
 
+def test_baseline_config3_size_rows_independent(ccx_ctx):
+    """BASELINE configs[2]: 16 x 8 s 8 kHz mixtures ([16, 64000] -> [16, 64000, 2]) at full depth.  The oracle takes minutes
+    at this size, so the check is the size-independent property: every row equals the same utterance separated alone
+    (ragged lengths included), rows past an utterance's length are zero, everything is finite."""
+    from clearconverse_amd.separator import SepformerSeparator
+    dims = SepDims()
+    sd = synthetic_sepformer_state_dict(dims, seed=9)
+    m = SepformerSeparator(dims, sd, max_tokens=16 * 8100, max_utts=16, ctx=ccx_ctx)
+    try:
+        lens = [64000] * 12 + [48000, 32000, 8000, 640]
+        mix = _mix([64000] * 16).cuda()
+        out = m.separate_batch(mix, lens)
+        assert out.shape == (16, 64000, 2) and torch.isfinite(out).all()
+        for b in (0, 7, 12, 15):
+            alone = m.separate_batch(mix[b:b + 1, :lens[b]].contiguous(), [lens[b]])
+            assert torch.equal(out[b, :lens[b]], alone[0])
+            if lens[b] < 64000:
+                assert float(out[b, lens[b]:].abs().max()) == 0.0
+    finally:
+        m.close()
+
+
 def test_rejects_too_short_input(small):
     dims, sd, m = small
     from clearconverse_amd._lib import CcxError
