@@ -277,6 +277,30 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
         m.close()
 
 
+def test_uneven_lane_partition_matches_small_batch(ccx_ctx, monkeypatch):
+    """100 sequences in 3 lanes are cut 48 / 48 / 4: the last lane takes the small-batch kernel path, the others the
+    large-batch one, each on its own stream and graph -- every sequence must still decode exactly as in a batch of 4."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=100, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        m.log_mel(dev, n); m.encode(4)
+        prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
+        a = m.decode_greedy(prompts, sample_len=12)
+        big = dev.repeat(25, 1).contiguous()
+        m.log_mel(big, n * 25); m.encode(100)
+        monkeypatch.setenv("CCX_DEC_LANES", "3")
+        b = m.decode_greedy(prompts * 25, sample_len=12)
+        for i in range(100):
+            assert b[i]["tokens"] == a[i % 4]["tokens"], i
+            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-4
+    finally:
+        m.close()
+
+
 def test_long_audio_multi_window_logmel_and_transcribe(ccx_ctx):
     """Audio longer than 30 s: the log-mel is normalised over the WHOLE clip and transcribe() walks 30 s
     windows with `seek` (transcribe.py main loop)."""
