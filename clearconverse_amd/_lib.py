@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ccx_prof_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _fp]),
     "ccx_gemm_bf16": (_i, [_vp, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "ccx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ccx_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
     "ccx_peak_normalize": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _vp]),
     "ccx_enc_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ccx_whisper_create": (_i, [_vp, C.POINTER(WhisperDims), _i, C.POINTER(_vp)]),

@@ -43,6 +43,21 @@ class BatchPipeline:
                                                        float(eps), _lib.current_stream_ptr()), "ccx_peak_normalize")
         return y
 
+    def _pad_batch(self, crops: List[torch.Tensor]):
+        """Ragged 1-D device crops -> (padded [n, max_len] f32 buffer, lengths).  One gather launch (ccx_gather_rows)
+        instead of one copy per crop; columns past a crop's length are uninitialised (the kernels read [:n] only)."""
+        n = [int(c.numel()) for c in crops]
+        dev = crops[0].device
+        buf = torch.empty(len(crops), max(n), device=dev, dtype=torch.float32)
+        for c in crops:
+            assert c.is_cuda and c.dtype == torch.float32 and (c.dim() == 1 or c.is_contiguous()) and c.stride(-1) == 1
+        ptrs = torch.tensor([c.data_ptr() for c in crops], dtype=torch.int64).to(dev, non_blocking=False)
+        lens = torch.tensor(n, dtype=torch.int32).to(dev, non_blocking=False)
+        self.ctx.check(self.ctx.lib.ccx_gather_rows(self.ctx.handle, ptrs.data_ptr(), lens.data_ptr(), len(crops), max(n), buf.data_ptr(),
+                                                    buf.shape[1], _lib.current_stream_ptr()), "ccx_gather_rows")
+        self._keep = (ptrs, lens)          # the tables must outlive the asynchronous launch
+        return buf, n
+
     def _whisper(self, crops: List[torch.Tensor], prompts: List[str]) -> List[dict]:
         """One 30 s window per crop (pinned schedule: every crop <= 30 s), batched in groups."""
         w = self.m["whisper_model"]
@@ -50,10 +65,7 @@ class BatchPipeline:
         out: List[dict] = []
         for i0 in range(0, len(crops), min(self.group, w.max_batch)):
             grp = crops[i0:i0 + min(self.group, w.max_batch)]
-            n = [int(c.numel()) for c in grp]
-            buf = torch.empty(len(grp), max(n), device=w.device, dtype=torch.float32)   # kernels read only [:n_samples]
-            for j, c in enumerate(grp):
-                buf[j, :n[j]] = c
+            buf, n = self._pad_batch(grp)                                               # kernels read only [:n_samples]
             w.log_mel(buf, n)
             w.encode(len(grp))
             pr = [w.initial_tokens(tok.encode(" " + p.strip()) if p else []) for p in prompts[i0:i0 + len(grp)]]
@@ -89,10 +101,7 @@ class BatchPipeline:
         # 3. speaker profiles from the scheduled turns (all >= 0.75 s): gate each crop, normalise, embed (A8)
         sched = [(spk, int(s * SR), int(e * SR)) for spk, s, e in SCHEDULE_30S]
         crops = [den[b, s:e] for b in range(B) for _, s, e in sched]
-        n = [int(c.numel()) for c in crops]
-        buf = torch.empty(len(crops), max(n), device=audio.device)
-        for i, c in enumerate(crops):
-            buf[i, :n[i]] = c
+        buf, n = self._pad_batch(crops)
         clean = self._peak(m["denoiser"].reduce_batch(buf, n, self.nra), n, 0.0)
         pe = m["embedding_model"].embed_batch([clean[i, :n[i]] for i in range(len(crops))])
         var = torch.stack([torch.var(c) for c in crops])   # embedding quality = variance of the raw crop (reference 939)
@@ -135,9 +144,7 @@ class BatchPipeline:
             regions += [(b, "A" if spk == "A" else "B", s, cut), (b, "B" if spk == "A" else "A", cut, e)]
         rcrops = [den[b, s:e] for b, _, s, e in regions]
         rn = [int(c.numel()) for c in rcrops]
-        rbuf = torch.empty(len(rcrops), max(rn), device=audio.device)
-        for i, c in enumerate(rcrops):
-            rbuf[i, :rn[i]] = c
+        rbuf, _ = self._pad_batch(rcrops)
         sep = []
         i0 = 0
         while i0 < len(rcrops):        # greedy groups under the separator's token capacity (frames, padded to chunks)

@@ -104,6 +104,12 @@ int ccx_peak_normalize(ccx_ctx* ctx, const float* x, float* y, int64_t stride, c
   return ccx_launch_peak_normalize(ctx, x, y, (long)stride, n_samples_dev, B, eps, (hipStream_t)stream);
 }
 
+int ccx_gather_rows(ccx_ctx* ctx, const int64_t* src_ptrs_dev, const int* lens_dev, int n_rows, int max_len, float* dst_dev,
+                    int64_t stride, void* stream) {
+  if (!ctx) return CCX_ERR_ARG;
+  return ccx_launch_gather_rows(ctx, (const long*)src_ptrs_dev, lens_dev, n_rows, max_len, dst_dev, (long)stride, (hipStream_t)stream);
+}
+
 int ccx_enc_attention(ccx_ctx* ctx, const void* q, const void* k, const void* vt, void* o, int B, int H, int S, int Spad,
                       void* stream) {
   if (!ctx) return CCX_ERR_ARG;

@@ -10,3 +10,6 @@ int ccx_launch_f32_to_bf16(ccx_ctx* ctx, const float* src, bf16_t* dst, long n, 
 int ccx_launch_fill_u16(ccx_ctx* ctx, bf16_t* dst, bf16_t v, long n, hipStream_t stream);
 int ccx_launch_peak_normalize(ccx_ctx* ctx, const float* x, float* y, long stride, const int* n_samples_dev, int B, float eps,
                               hipStream_t stream);
+// dst[i][0 .. lens[i]) = ((const float*)src_ptrs[i])[0 .. lens[i]); tables in device memory
+int ccx_launch_gather_rows(ccx_ctx* ctx, const long* src_ptrs_dev, const int* lens_dev, int n_rows, int max_len, float* dst,
+                           long stride, hipStream_t stream);

@@ -99,6 +99,34 @@ int ccx_launch_peak_normalize(ccx_ctx* ctx, const float* x, float* y, long strid
   return CCX_OK;
 }
 
+// dst[i][0 .. len_i) = src_i[0 .. len_i): ragged crops (row pointers and lengths in device tables) into a padded batch,
+// one launch instead of one copy per crop.  Columns past len_i are left untouched.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const long* __restrict__ src_ptrs, const int* __restrict__ lens,
+                                                          float* __restrict__ dst, long stride) {
+  const int row = blockIdx.y;
+  const int n = lens[row];
+  const float* src = (const float*)src_ptrs[row];
+  float* d = dst + (long)row * stride;
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int j = i + 256 * k;
+      if (j < n) d[j] = src[j];
+    }
+  }
+}
+
+int ccx_launch_gather_rows(ccx_ctx* ctx, const long* src_ptrs_dev, const int* lens_dev, int n_rows, int max_len, float* dst,
+                           long stride, hipStream_t stream) {
+  CCX_REQUIRE(ctx, src_ptrs_dev && lens_dev && dst && n_rows >= 1 && max_len >= 0 && stride >= max_len, "gather_rows: bad arguments");
+  if (max_len == 0) return CCX_OK;
+  int bx = ccx_cdiv(max_len, 1024);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, n_rows), dim3(256), 0, stream, src_ptrs_dev, lens_dev, dst, stride);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
 int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* gamma, const float* beta,
                          bf16_t* out_bf16, float* out_f32, long ldo, int M, int D, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);

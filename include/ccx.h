@@ -57,6 +57,10 @@ int ccx_layernorm(ccx_ctx* ctx, const float* x_dev, const float* gamma_dev, cons
 /* Peak normalisation y = x / (max|x| + eps) per row (eps == 0: only when the peak is > 0) -- replaces
  * `signal_np / (np.max(np.abs(signal_np)) + 1e-8)` (reference back/api.py:834) and lines 350-351.
  * x,y [B, stride] f32 (may alias), n_samples_dev [B] int32 on the device. */
+/* Ragged crops into a padded batch in one launch (the reference slices one crop at a time, `_extract_segment`,
+ * back/api.py:840-860): dst[i][0 .. lens[i]) = row i, whose device address is src_ptrs_dev[i]; both tables in device memory. */
+int ccx_gather_rows(ccx_ctx* ctx, const int64_t* src_ptrs_dev, const int* lens_dev, int n_rows, int max_len, float* dst_dev,
+                    int64_t stride, void* stream);
 int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t stride, const int* n_samples_dev, int B,
                        float eps, void* stream);
 

@@ -103,3 +103,21 @@ def test_enc_attention(ccx_ctx, B, H, S):
     # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative
     assert _rel(got, ref) < 1e-2, _rel(got, ref)
     assert float((got - ref).abs().max()) < 0.06
+
+
+def test_gather_rows_ragged(ccx_ctx):
+    """ccx_gather_rows: ragged crops (arbitrary 4-byte-aligned starts, lengths 1 .. 9000) into a padded batch, bit-exact;
+    columns past a crop's length stay untouched."""
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(3, 20000, generator=g).cuda()
+    spans = [(0, 0, 9000), (1, 3, 1), (2, 19999, 1), (0, 1234, 4097), (1, 7, 1024), (2, 5000, 1023)]
+    crops = [src[b, s:s + n] for b, s, n in spans]
+    ptrs = torch.tensor([c.data_ptr() for c in crops], dtype=torch.int64).cuda()
+    lens = torch.tensor([n for _, _, n in spans], dtype=torch.int32).cuda()
+    dst = torch.full((len(spans), 9000), -7.0, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_gather_rows(ccx_ctx.handle, ptrs.data_ptr(), lens.data_ptr(), len(spans), 9000, dst.data_ptr(), 9000,
+                                              _stream()), "ccx_gather_rows")
+    torch.cuda.synchronize()
+    for i, (b, s, n) in enumerate(spans):
+        assert torch.equal(dst[i, :n], src[b, s:s + n])
+        assert bool((dst[i, n:] == -7.0).all())
