@@ -104,7 +104,12 @@ class BatchPipeline:
         buf, n = self._pad_batch(crops)
         clean = self._peak(m["denoiser"].reduce_batch(buf, n, self.nra), n, 0.0)
         pe = m["embedding_model"].embed_batch([clean[i, :n[i]] for i in range(len(crops))])
-        var = torch.stack([torch.var(c) for c in crops])   # embedding quality = variance of the raw crop (reference 939)
+        # embedding quality = unbiased variance of the raw crop (reference 939): two masked passes over the padded batch
+        # instead of one torch.var launch chain per crop
+        nn = torch.tensor(n, device=buf.device, dtype=torch.float32)
+        msk = torch.arange(buf.shape[1], device=buf.device)[None, :] < nn[:, None]
+        mean = torch.where(msk, buf, 0.0).sum(dim=1) / nn
+        var = torch.where(msk, (buf - mean[:, None]) ** 2, 0.0).sum(dim=1) / (nn - 1.0)
         profiles = []
         for b in range(B):
             prof = {}
