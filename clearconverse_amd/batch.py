@@ -110,14 +110,14 @@ class BatchPipeline:
         msk = torch.arange(buf.shape[1], device=buf.device)[None, :] < nn[:, None]
         mean = torch.where(msk, buf, 0.0).sum(dim=1) / nn
         var = torch.where(msk, (buf - mean[:, None]) ** 2, 0.0).sum(dim=1) / (nn - 1.0)
-        profiles = []
-        for b in range(B):
-            prof = {}
-            for spk in ("A", "B"):
-                idx = [b * len(sched) + j for j, (s_, _, _) in enumerate(sched) if s_ == spk]
-                wts = var[idx] / var[idx].sum()
-                prof[spk] = (pe[idx] * wts[:, None]).sum(dim=0)
-            profiles.append(prof)
+        # variance-weighted sum of each speaker's turn embeddings (not re-normalised, reference 946-953), all clips at once
+        pe_c, var_c = pe.view(B, len(sched), -1), var.view(B, len(sched))
+        prof_all = {}
+        for spk in ("A", "B"):
+            cols = [j for j, (s_, _, _) in enumerate(sched) if s_ == spk]
+            wts = var_c[:, cols] / var_c[:, cols].sum(dim=1, keepdim=True)
+            prof_all[spk] = (pe_c[:, cols] * wts[..., None]).sum(dim=1)          # [B, D]
+        profiles = [{spk: prof_all[spk][b] for spk in ("A", "B")} for b in range(B)]
         t = self._mark("profiles", t, timed)
         # 4. regular segments (A 18-24, B 26-30): embed + similarity, then Whisper with the fixed prompt
         reg = [(b, spk, s, e) for b in range(B) for spk, s, e in sched[2:]]
