@@ -119,18 +119,31 @@ def binarize(score: np.ndarray, onset: float, offset: float, min_on: float = 0.0
              frame_step: float = FRAME_STEP, t0: float = 0.5 * FRAME_DUR) -> List[Tuple[float, float]]:
     """Hysteresis thresholding of a 1-D frame score (pyannote Binarize): on above `onset`, off below `offset`;
     then fill gaps < min_off and drop regions < min_on.  Frame i is centred at t0 + i*frame_step."""
-    regions: List[Tuple[float, float]] = []
-    active, start = False, 0.0
+    score = np.asarray(score)
     times = t0 + frame_step * np.arange(score.shape[0])
-    for t, y in zip(times, score):
+    regions: List[Tuple[float, float]] = []
+    if score.shape[0] and onset >= offset:
+        # vectorised state machine: +1 events switch on, -1 events switch off, every other frame keeps the state of the
+        # last event before it (forward fill); a region starts at the frame that switches on and ends at the frame that
+        # switches off (or at the last frame)
+        ev = np.where(score > onset, 1, np.where(score < offset, -1, 0)).astype(np.int8)
+        last = np.maximum.accumulate(np.where(ev != 0, np.arange(ev.shape[0]), -1))
+        active = np.where(last >= 0, ev[np.maximum(last, 0)], -1) == 1
+        d = np.diff(np.concatenate([[False], active]).astype(np.int8))
+        starts, ends = np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+        for k, s_i in enumerate(starts):
+            regions.append((float(times[s_i]), float(times[ends[k]] if k < len(ends) else times[-1])))
+    else:
+        active, start = False, 0.0
+        for t, y in zip(times, score):
+            if active:
+                if y < offset:
+                    regions.append((start, float(t)))
+                    active = False
+            elif y > onset:
+                start, active = float(t), True
         if active:
-            if y < offset:
-                regions.append((start, float(t)))
-                active = False
-        elif y > onset:
-            start, active = float(t), True
-    if active:
-        regions.append((start, float(times[-1])))
+            regions.append((start, float(times[-1])))
     merged: List[Tuple[float, float]] = []
     for s, e in regions:
         if merged and s - merged[-1][1] < min_off:
@@ -351,13 +364,10 @@ class SpeakerDiarization:
         n_clusters = int(labels.max()) + 1
         if n_clusters <= 0:
             return Annotation([])
-        clustered = []
-        for ci, m in enumerate(multi):
-            act = np.zeros((m.shape[0], n_clusters), dtype=np.float32)
-            for (kc, sp), lab in zip(keys, labels):
-                if kc == ci and lab >= 0:
-                    act[:, lab] = np.maximum(act[:, lab], m[:, sp])
-            clustered.append(act)
+        clustered = [np.zeros((m.shape[0], n_clusters), dtype=np.float32) for m in multi]
+        for (kc, sp), lab in zip(keys, labels):                            # one pass over the (window, local speaker) keys
+            if lab >= 0:
+                np.maximum(clustered[kc][:, lab], multi[kc][:, sp], out=clustered[kc][:, lab])
         agg = aggregate(clustered, starts, n_samples, self.win)          # [frames, clusters]
         n_valid = min(agg.shape[0], int(n_samples / 270))
         agg, count = agg[:n_valid], count[:n_valid]

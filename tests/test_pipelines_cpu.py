@@ -53,3 +53,41 @@ def test_annotation_contract():
     ann = P.Annotation([(2.0, 3.0, "SPEAKER_01"), (0.5, 1.5, "SPEAKER_00")])
     got = [(seg.start, seg.end, lab) for seg, _, lab in ann.itertracks(yield_label=True)]
     assert got == [(0.5, 1.5, "SPEAKER_00"), (2.0, 3.0, "SPEAKER_01")]
+
+
+def test_binarize_vectorised_state_machine_equals_the_loop():
+    """The numpy forward-fill form of the hysteresis state machine against the frame-by-frame loop it replaces, on random
+    scores (plateaus exactly at the thresholds included)."""
+    from clearconverse_amd.pipelines import FRAME_DUR, FRAME_STEP, binarize
+
+    def loop(score, onset, offset, min_on, min_off):
+        times = 0.5 * FRAME_DUR + FRAME_STEP * np.arange(score.shape[0])
+        regions, active, start = [], False, 0.0
+        for t, y in zip(times, score):
+            if active:
+                if y < offset:
+                    regions.append((start, float(t))); active = False
+            elif y > onset:
+                start, active = float(t), True
+        if active:
+            regions.append((start, float(times[-1])))
+        merged = []
+        for s, e in regions:
+            if merged and s - merged[-1][1] < min_off:
+                merged[-1] = (merged[-1][0], e)
+            else:
+                merged.append((s, e))
+        return [(s, e) for s, e in merged if e - s >= min_on and e > s]
+
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n = int(rng.integers(0, 400))
+        score = np.round(rng.random(n), 1)                       # many exact ties with the thresholds
+        onset = float(rng.choice([0.3, 0.5, 0.7, 0.767]))
+        offset = float(rng.choice([0.2, 0.3, 0.377, onset]))
+        if offset > onset:
+            offset = onset
+        min_on, min_off = float(rng.choice([0.0, 0.136])), float(rng.choice([0.0, 0.067]))
+        assert binarize(score, onset, offset, min_on, min_off) == loop(score, onset, offset, min_on, min_off), trial
+    assert binarize(np.zeros(0), 0.5, 0.5) == []
+    assert binarize(np.array([0.9]), 0.5, 0.4) == []             # a single active frame has zero length
