@@ -325,7 +325,7 @@ class SpeakerDiarization:
                 keys.append((ci, sp))
                 e_crops.append(i0 + ci)
                 e_weights.append(torch.from_numpy(w.astype(np.float32)))
-            per_item.append((starts, multi, keys))
+            per_item.append((starts, multi, keys, list(multi_all.sum(axis=-1, keepdims=True))))   # + active speakers per frame
         if not e_crops:
             embs = None
         elif hasattr(self.emb, "embed_chunks"):
@@ -348,14 +348,16 @@ class SpeakerDiarization:
             if it is None or not it[2]:
                 anns.append(Annotation([]))
                 continue
-            starts, multi, keys = it
-            anns.append(self._reconstruct(len(x), starts, multi, keys, embs[e0:e0 + len(keys)], lo, hi))
+            starts, multi, keys, n_active = it
+            anns.append(self._reconstruct(len(x), starts, multi, keys, embs[e0:e0 + len(keys)], lo, hi, n_active))
             e0 += len(keys)
         return anns
 
-    def _reconstruct(self, n_samples: int, starts, multi, keys, embs, lo: int, hi: int) -> Annotation:
+    def _reconstruct(self, n_samples: int, starts, multi, keys, embs, lo: int, hi: int, n_active=None) -> Annotation:
         dur = n_samples / SR
-        count = np.rint(aggregate([m.sum(axis=-1, keepdims=True) for m in multi], starts, n_samples, self.win)[:, 0]).astype(np.int64)
+        if n_active is None:
+            n_active = [m.sum(axis=-1, keepdims=True) for m in multi]
+        count = np.rint(aggregate(n_active, starts, n_samples, self.win)[:, 0]).astype(np.int64)
         count = np.minimum(count, hi)
         ok = np.isfinite(embs).all(axis=1)
         labels = np.full(len(keys), -1, dtype=np.int64)
