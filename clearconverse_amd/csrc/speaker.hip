@@ -243,59 +243,110 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// LSTM recurrence.  grid (crop, direction); 512 threads = the 512 gate rows (i|f|g|o x 128), each
-// keeping its W_hh row (128 f32) in registers; h lives in LDS and is broadcast-read as float4.
-// gx: [rows][1024] f32 = x W_ih^T + b_ih + b_hh (fwd 0..511 | rev 512..1023) from the MFMA GEMM.
-// hout: [rows][256] bf16 (fwd h | rev h).
+// LSTM recurrence on the matrix cores.  grid (ceil(crops / 16), direction); a block advances 16 crops
+// together: gates[16 x 512] = H[16 x 128] x W_hh^T as v_mfma_f32_16x16x32_bf16 with fp32 accumulate.
+//   * wave w owns hidden units 16w..16w+15 and all four of their gates (i|f|g|o): its 16 W_hh fragments
+//     (4 gates x K = 128) stay in registers for the whole sequence, and the cell update of a unit is
+//     lane-local (the accumulators of the four gates line up register by register);
+//   * H lives in LDS as bf16 (two buffers, 272-byte rows: conflict-free ds_read_b128 by 16 rows), one
+//     barrier per step;
+//   * the accumulators start from gx (x W_ih^T + b_ih + b_hh, fp32, from the GEMM), fetched three
+//     steps ahead of use.
+// Rows of the MFMA are independent, so a crop's result does not depend on its block mates.
+// gx: [rows][1024] f32 (fwd 0..511 | rev 512..1023);  whh: [2][512][128] bf16;  hout: [rows][256] bf16 (fwd h | rev h).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __restrict__ gx, const float* __restrict__ whh,  // [2][512][128]
-                                                             const int* __restrict__ row_off, const int* __restrict__ n_rows,
+#define LSTM_SEQS 16
+__global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __restrict__ gx, const bf16_t* __restrict__ whh,
+                                                             const int* __restrict__ row_off, const int* __restrict__ n_rows, int n_crops,
                                                              bf16_t* __restrict__ hout) {
-  __shared__ __attribute__((aligned(16))) float hs[128];
-  __shared__ float gate[512];
-  const int crop = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
-  const int n = n_rows[crop];
-  const long r0 = row_off[crop];
-  typedef __attribute__((ext_vector_type(2))) float f2;
-  f2 w[64];   // this thread's W_hh row as 64 pairs: the dot product below compiles to v_pk_fma_f32 (2 FMAs per lane and issue)
-  {
-    const float4* wp = (const float4*)(whh + ((long)dir * 512 + j) * 128);
+  __shared__ __attribute__((aligned(16))) bf16_t Hs[2][LSTM_SEQS][136];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, hq = lane >> 4;
+  const int dir = blockIdx.y, c0 = blockIdx.x * LSTM_SEQS;
+  const int unit = 16 * wave + l15;
+
+  bf16x8 wf[4][4];   // [gate][k step]: B operand, column = unit, k = 32 kk + 8 hq ..
 #pragma unroll
-    for (int k = 0; k < 32; k++) { const float4 v = wp[k]; w[2 * k] = (f2){v.x, v.y}; w[2 * k + 1] = (f2){v.z, v.w}; }
+  for (int g = 0; g < 4; g++)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+      wf[g][kk] = *(const bf16x8*)(whh + ((long)dir * 512 + g * 128 + unit) * 128 + 32 * kk + 8 * hq);
+
+  // this lane's four crops are the accumulator rows 4 hq + r
+  int nr[4];
+  const float* gbase[4];
+  bf16_t* hbase[4];
+  int nmax = 0;
+  for (int q = 0; q < LSTM_SEQS; q++) {
+    const int n = c0 + q < n_crops ? n_rows[c0 + q] : 0;
+    nmax = n > nmax ? n : nmax;
   }
-  if (j < 128) hs[j] = 0.f;
-  float c = 0.f;
-  __syncthreads();
-  int t = dir == 0 ? 0 : n - 1;
-  float gnext = n > 0 ? gx[(r0 + t) * 1024 + dir * 512 + j] : 0.f;
-  for (int step = 0; step < n; step++) {
-    const float g0 = gnext;
-    const int tn = dir == 0 ? t + 1 : t - 1;
-    if (step + 1 < n) gnext = gx[(r0 + tn) * 1024 + dir * 512 + j];   // prefetch, independent of h
-    f2 a0 = (f2){0.f, 0.f}, a1 = (f2){0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-      const float4 h4 = ((const float4*)hs)[k];
-      // the compiler splits a 2-vector fma into two v_fmac_f32; the packed form issues both in one VALU slot
-      const f2 h01 = (f2){h4.x, h4.y}, h23 = (f2){h4.z, h4.w};
-      asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(w[2 * k]), "v"(h01));
-      asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(w[2 * k + 1]), "v"(h23));
+  for (int r = 0; r < 4; r++) {
+    const int crop = c0 + 4 * hq + r;
+    nr[r] = crop < n_crops ? n_rows[crop] : 0;
+    const long r0 = crop < n_crops ? row_off[crop] : 0;
+    gbase[r] = gx + r0 * 1024 + dir * 512 + unit;
+    hbase[r] = hout + r0 * 256 + dir * 128 + unit;
+  }
+  for (int i = tid; i < 2 * LSTM_SEQS * 136; i += 512) (&Hs[0][0][0])[i] = 0;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+  float gq[4][4][4];   // [ring slot][gate][row]: gx of steps s .. s+3
+  auto fetch = [&](int step, int slot) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (step < nr[r]) {
+        const int t = dir == 0 ? step : nr[r] - 1 - step;
+        const float* gp = gbase[r] + (long)t * 1024;
+#pragma unroll
+        for (int g = 0; g < 4; g++) gq[slot][g][r] = gp[g * 128];
+      }
     }
-    // every thread applies its own gate non-linearity (rows 0..127 i, 128..255 f, 256..383 g, 384..511 o), so the
-    // serial part after the barrier is one tanh per cell.  tanh(x) = 1 - 2 / (exp(2x) + 1): ~1e-7 abs in fp32.
-    const float pre = g0 + (a0.x + a0.y) + (a1.x + a1.y);
-    const bool is_g = (j >> 7) == 2;
-    const float ex = __expf(is_g ? 2.f * pre : -pre);
-    gate[j] = is_g ? 1.f - 2.f / (ex + 1.f) : 1.f / (1.f + ex);
-    __syncthreads();
-    if (j < 128) {
-      c = gate[128 + j] * c + gate[j] * gate[256 + j];
-      const float h = gate[384 + j] * (1.f - 2.f / (__expf(2.f * c) + 1.f));
-      hs[j] = h;
-      hout[(r0 + t) * 256 + dir * 128 + j] = f32_to_bf16(h);
+  };
+  fetch(0, 0); fetch(1, 1); fetch(2, 2);
+  __syncthreads();
+  for (int s0 = 0; s0 < nmax; s0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int step = s0 + u;
+      if (step >= nmax) break;            // uniform over the block
+      fetch(step + 3, (u + 3) & 3);
+      const bf16_t(*Hc)[136] = Hs[step & 1];
+      bf16_t(*Hn)[136] = Hs[(step + 1) & 1];
+      f32x4 acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = (f32x4){gq[u][g][0], gq[u][g][1], gq[u][g][2], gq[u][g][3]};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const bf16x8 a = *(const bf16x8*)&Hc[l15][32 * kk + 8 * hq];   // A operand: row = crop l15
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[g][kk], acc[g], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        if (step < nr[r]) {
+          // sigmoid(x) = 1 / (1 + e^-x), tanh(x) = (1 - e^-2x) / (1 + e^-2x), over ONE common denominator per
+          // product: c' = f c + i tanh(g) = [c (1+ei)(1+eg) + (1-eg)(1+ef)] / [(1+ef)(1+ei)(1+eg)] and
+          // h = o tanh(c') = (1-ec) / [(1+eo)(1+ec)]  -- 5 v_exp + 2 v_rcp per cell (the gate math, not the MFMAs,
+          // is the serial part of a step).  Exponents are clamped to +-25 so the triple product stays finite
+          // (sigmoid(-25) = 1.4e-11: below fp32 resolution of the sums it enters).
+          constexpr float L2E = 1.4426950408889634f, CL = 25.f;
+          const float ei = __builtin_amdgcn_exp2f(-L2E * fminf(fmaxf(acc[0][r], -CL), CL));
+          const float ef = __builtin_amdgcn_exp2f(-L2E * fminf(fmaxf(acc[1][r], -CL), CL));
+          const float eg = __builtin_amdgcn_exp2f(-L2E * fminf(fmaxf(2.f * acc[2][r], -CL), CL));
+          const float eo = __builtin_amdgcn_exp2f(-L2E * fminf(fmaxf(acc[3][r], -CL), CL));
+          const float ab = (1.f + ei) * (1.f + eg), ff = 1.f + ef;
+          c[r] = fmaf(c[r], ab, (1.f - eg) * ff) * __builtin_amdgcn_rcpf(ff * ab);
+          const float ec = __builtin_amdgcn_exp2f(-L2E * fminf(fmaxf(2.f * c[r], -CL), CL));
+          const bf16_t hb = f32_to_bf16((1.f - ec) * __builtin_amdgcn_rcpf((1.f + eo) * (1.f + ec)));
+          const int t = dir == 0 ? step : nr[r] - 1 - step;
+          Hn[4 * hq + r][unit] = hb;
+          hbase[r][(long)t * 256] = hb;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    t = tn;
   }
 }
 
@@ -355,7 +406,7 @@ struct ccx_speaker {
   float *bt[5] = {}, *sct[5] = {}, *sht[5] = {};
   bf16_t* Wemb = nullptr; float* bemb = nullptr;
   // pyannet
-  bf16_t* Wih[4] = {}; float* bih[4] = {}; float* whh[4] = {};
+  bf16_t* Wih[4] = {}; float* bih[4] = {}; bf16_t* whh[4] = {};
   bf16_t *Wl0 = nullptr, *Wl1 = nullptr, *Wcls = nullptr; float *bl0 = nullptr, *bl1 = nullptr, *bcls = nullptr;
   // workspaces
   long R1cap = 0;
@@ -586,7 +637,7 @@ int ccx_speaker_finalize(ccx_speaker* s) {
           for (int k = 0; k < 128; k++) whh[((size_t)dir * 512 + r) * 128 + k] = wh->data[(size_t)r * 128 + k];
         }
       }
-      PTRY(pup_bf16(s, &s->Wih[l], wih)); PTRY(pup_f32(s, &s->bih[l], bias.data(), 1024)); PTRY(pup_f32(s, &s->whh[l], whh.data(), whh.size()));
+      PTRY(pup_bf16(s, &s->Wih[l], wih)); PTRY(pup_f32(s, &s->bih[l], bias.data(), 1024)); PTRY(pup_bf16(s, &s->whh[l], whh));
     }
     PNEED(l0w, "linear.0.weight", 128 * 256); PNEED(l0b, "linear.0.bias", 128);
     PNEED(l1w, "linear.1.weight", 128 * 128); PNEED(l1b, "linear.1.bias", 128);
@@ -704,7 +755,7 @@ int ccx_speaker_segment(ccx_speaker* s, const float* wav, const int64_t* offsets
     PTRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
     {
       ccx_prof_scope ps(ctx, st, "lstm_recurrent_kernel", 0.0, 0.0);
-      hipLaunchKernelGGL(lstm_recurrent_kernel, dim3(n, 2), dim3(512), 0, st, s->gx, s->whh[l], s->off3, s->nF3, hbuf[l & 1]);
+      hipLaunchKernelGGL(lstm_recurrent_kernel, dim3(ccx_cdiv(n, LSTM_SEQS), 2), dim3(512), 0, st, s->gx, s->whh[l], s->off3, s->nF3, n, hbuf[l & 1]);
     }
     CCX_CHECK_LAUNCH(ctx);
     x = hbuf[l & 1]; ldx = 256; K = 256;

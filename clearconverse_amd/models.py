@@ -48,7 +48,8 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
 
 def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
-                sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None) -> Dict[str, object]:
+                sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
+                seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0) -> Dict[str, object]:
     if not torch.cuda.is_available():
         raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
     dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
@@ -65,10 +66,13 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     # embedding model of the diarization pipeline (speaker-diarization-3.1 uses WeSpeaker ResNet-34, not pyannote/embedding)
     diar_embedder = ResNetEmbedder(W["resnet34"], max_chunks=96, max_samples=160000, max_masks=512,
                                    device=dev_index, ctx=ctx)
-    seg_diar = SegmentationNet(W["pyannet_diar"], n_classes=7, powerset=True, max_crops=max_crops,
-                               max_samples=16000 * 1200, device=dev_index, ctx=ctx)
-    seg_vad = SegmentationNet(W["pyannet_vad"], n_classes=3, powerset=False, max_crops=max_crops,
-                              max_samples=16000 * 1200, device=dev_index, ctx=ctx)
+    # one launch group of the segmentation nets holds seg_max_crops windows / seg_max_seconds of audio (≈60 B of device
+    # buffers per sample): the batched pipeline raises both so that every window of a step shares one LSTM launch
+    seg_crops = int(seg_max_crops or max_crops)
+    seg_diar = SegmentationNet(W["pyannet_diar"], n_classes=7, powerset=True, max_crops=seg_crops,
+                               max_samples=int(16000 * seg_max_seconds), device=dev_index, ctx=ctx)
+    seg_vad = SegmentationNet(W["pyannet_vad"], n_classes=3, powerset=False, max_crops=seg_crops,
+                              max_samples=int(16000 * seg_max_seconds), device=dev_index, ctx=ctx)
     gate = SpectralGate(max_samples=480000, max_clips=32, device=dev_index, ctx=ctx)
     return {
         "ctx": ctx,
@@ -76,8 +80,8 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
         "whisper_model": whisper,
         "separator": separator,
         "embedding_model": embedder,
-        "vad_pipeline": VoiceActivityDetection(seg_vad, batch=max_crops),
-        "diarization": SpeakerDiarization(seg_diar, diar_embedder, batch=max_crops),
+        "vad_pipeline": VoiceActivityDetection(seg_vad, batch=seg_crops),
+        "diarization": SpeakerDiarization(seg_diar, diar_embedder, batch=seg_crops),
         "diarization_embedder": diar_embedder,
         "denoiser": gate,
         "segmentation_vad": seg_vad,

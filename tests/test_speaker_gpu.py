@@ -103,3 +103,31 @@ def test_pyannet_matches_oracle(ccx_ctx, powerset, n_classes):
         assert outs[0].shape[0] == 589
     finally:
         m.close()
+
+
+def test_pyannet_block_mates_and_ragged_groups(ccx_ctx):
+    """The LSTM advances 16 windows per block on the matrix cores: a window's scores must not depend on which windows
+    share its block, on its row inside the block, or on ragged lengths in the same block (37 windows = 2 full blocks +
+    a partial one per direction)."""
+    from clearconverse_amd.speaker import SegmentationNet
+    sd = synthetic_pyannet_state_dict(7, seed=5)
+    m = SegmentationNet(sd, n_classes=7, powerset=True, max_crops=64, max_samples=16000 * 400, ctx=ccx_ctx)
+    try:
+        lens = [80000, 160000, 20000, 48000, 80000, 33000, 160000] * 5 + [80000, 12000]
+        crops = _crops(lens)
+        together = m.segment_numpy(crops)
+        assert [t.shape[0] for t in together] == [m.segment_numpy([c])[0].shape[0] for c in crops[:3]] + [t.shape[0] for t in together[3:]]
+        for i in (0, 1, 2, 5, 15, 16, 17, 31, 35, 36):
+            alone = m.segment_numpy([crops[i]])[0]
+            assert np.array_equal(alone, together[i]), i
+        # a different order puts every window on another accumulator row
+        perm = list(reversed(range(len(crops))))
+        shuffled = m.segment_numpy([crops[i] for i in perm])
+        for k, i in enumerate(perm):
+            assert np.array_equal(shuffled[k], together[i]), i
+        # oracle check of a window that sits in the partial block
+        osd = dict(sd); osd["powerset"] = torch.tensor(1)
+        ref = P.pyannet_forward(osd, crops[36][None, None])[0]
+        assert float((torch.from_numpy(together[36]) - ref).abs().max()) < 5e-2
+    finally:
+        m.close()
