@@ -1,6 +1,6 @@
 """-m gpu: SincNet x-vector embedder and PyanNet segmentation through the C ABI vs
 oracle/pyannote_ref.py (CPU fp32).  Tolerances: embeddings rel-L2 <= 2e-2 (bf16 GEMM inputs, fp32
-sinc conv / norms / LSTM state); segmentation scores abs 5e-2 in log-prob, identical frame argmax
+sinc conv / norms / LSTM cell state; the LSTM's h and W_hh enter the matrix cores as bf16); segmentation scores abs 5e-2 in log-prob, identical frame argmax
 wherever the oracle's top-2 margin exceeds 0.1."""
 import numpy as np
 import pytest
