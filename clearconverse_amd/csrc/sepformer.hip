@@ -247,6 +247,190 @@ __global__ __launch_bounds__(256) void sep_final_norm_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused position-wise FFN of a layer (d_model = 128):   h += W2 relu(W1 LN(h) + b1) + b2   in place.
+// The two GEMMs of the unfused form move the d_ffn-wide hidden activation through HBM twice (4 KB of the
+// 8.7 KB a token costs per layer); here a token's row is read once and written once.
+//   * block = 8 waves x 32 tokens; a wave normalises its tokens in registers (a row sits in the four lanes
+//     l15, l15+16, +32, +48) and keeps them as bf16 B-operand fragments for the whole tile;
+//   * W1 / W2 stream through LDS by LDS-DMA in stages of 128 hidden units (32 KB + 32 KB, two stages),
+//     XOR-swizzled on the DMA source (ff_key: conflict-free ds_read_b128 per tools/lds_bank_sim.py);
+//   * MFMA operands are swapped as in gemm_bf16.hip (weights as "A"), so a lane owns 16 consecutive hidden
+//     units of its token after GEMM 1 -- exactly a k-group of GEMM 2's B operand: relu + bf16 in registers,
+//     no LDS round trip for the hidden activation.  The k order inside a 64-block is permuted to match
+//     (hidden 16 hq + 8 s + e at MFMA k position 8 hq + e of step s); the W2 fragments follow it;
+//   * the same permutation on GEMM 1's k axis makes the lane's input features its output features
+//     (64 ob + 16 hq + 0..15), so the epilogue adds bias and the residual row 64 B at a time.
+// ---------------------------------------------------------------------------------------------
+#define FF_TOK 256
+#define FF_HB 128
+#define FF_PART (FF_HB * 256)
+#define FF_STAGE (2 * FF_PART)
+typedef const __attribute__((address_space(1))) void* ff_gptr_t;
+typedef __attribute__((address_space(3))) void* ff_lptr_t;
+
+__device__ __forceinline__ int ff_key(int r) { return (r & 3) | (((r >> 4) & 3) << 2); }
+
+__global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                      const bf16_t* __restrict__ W1, const float* __restrict__ b1,
+                                                      const bf16_t* __restrict__ W2, const float* __restrict__ b2, int n_tok, int d_ffn,
+                                                      float eps) {
+  extern __shared__ __attribute__((aligned(16))) char ff_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, hq = lane >> 4;
+  const int tok0 = blockIdx.x * FF_TOK + wave * 32;
+  const int n_stage = d_ffn / FF_HB;
+
+  // ---- weight staging: DMA instruction i of a part covers its LDS rows 4i .. 4i+3 (256 B each) ----
+  const bf16_t* src1[4];
+  const bf16_t* src2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 4 + (lane >> 4);
+    const int gch = (lane & 15) ^ ff_key(row);
+    src1[i] = W1 + (long)row * 128 + gch * 8;      // + stage * FF_HB rows
+    src2[i] = W2 + (long)row * d_ffn + gch * 8;    // + stage * FF_HB columns
+  }
+  auto stage = [&](int st, int buf) {
+    char* s1 = ff_smem + buf * FF_STAGE;
+    char* s2 = s1 + FF_PART;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src1[i] + (long)st * FF_HB * 128), (ff_lptr_t)(s1 + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src2[i] + (long)st * FF_HB), (ff_lptr_t)(s2 + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  stage(0, 0);
+
+  // ---- LayerNorm of the wave's 32 tokens -> bf16 fragments xb[mt][ks] (features 64 (ks>>1) + 16 hq + 8 (ks&1) + 0..7) ----
+  bf16x8 xb[2][4];
+  {
+    float g[32], bt[32];
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; i4++) {
+        const float4 gv = ((const float4*)(ln_g + 64 * ob + 16 * hq))[i4], bv = ((const float4*)(ln_b + 64 * ob + 16 * hq))[i4];
+        g[16 * ob + 4 * i4] = gv.x; g[16 * ob + 4 * i4 + 1] = gv.y; g[16 * ob + 4 * i4 + 2] = gv.z; g[16 * ob + 4 * i4 + 3] = gv.w;
+        bt[16 * ob + 4 * i4] = bv.x; bt[16 * ob + 4 * i4 + 1] = bv.y; bt[16 * ob + 4 * i4 + 2] = bv.z; bt[16 * ob + 4 * i4 + 3] = bv.w;
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      int tok = tok0 + mt * 16 + l15;
+      tok = tok < n_tok ? tok : n_tok - 1;
+      const float* xr = h + (long)tok * 128 + 16 * hq;
+      float v[32];
+#pragma unroll
+      for (int ob = 0; ob < 2; ob++)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++) {
+          const float4 t = ((const float4*)(xr + 64 * ob))[i4];
+          v[16 * ob + 4 * i4] = t.x; v[16 * ob + 4 * i4 + 1] = t.y; v[16 * ob + 4 * i4 + 2] = t.z; v[16 * ob + 4 * i4 + 3] = t.w;
+        }
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; c++) sm += v[c];
+      sm += lane_xor16(sm); sm += lane_xor32(sm);
+      const float mean = sm * (1.f / 128.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; c++) { const float d = v[c] - mean; sq = fmaf(d, d, sq); }
+      sq += lane_xor16(sq); sq += lane_xor32(sq);
+      const float rstd = rsqrtf(sq * (1.f / 128.f) + eps);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        union { bf16x8 vv; uint32_t u[4]; } cv;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int c = 8 * ks + 2 * e;
+          cv.u[e] = pack_bf16x2((v[c] - mean) * rstd * g[c] + bt[c], (v[c + 1] - mean) * rstd * g[c + 1] + bt[c + 1]);
+        }
+        xb[mt][ks] = cv.vv;
+      }
+    }
+  }
+
+  f32x4 acc2[2][8];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int jo = 0; jo < 8; jo++) acc2[mt][jo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int rq = 16 * (l15 >> 2) + (l15 & 3);            // permuted operand row inside a 64-row block (+ 4 j)
+  const int kq = (l15 & 3) | ((l15 >> 2) << 2);          // ff_key of that row (independent of j and of the 64-block)
+  __syncthreads();
+  for (int st = 0; st < n_stage; st++) {
+    const int buf = st & 1;
+    if (st + 1 < n_stage) stage(st + 1, buf ^ 1);
+    const char* s1 = ff_smem + buf * FF_STAGE;
+    const char* s2 = s1 + FF_PART;
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++) {
+      f32x4 acc1[2][4];
+      {
+        const float4* bp = (const float4*)(b1 + st * FF_HB + 64 * sb + 16 * hq);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float4 bv = bp[j];
+          acc1[0][j] = (f32x4){bv.x, bv.y, bv.z, bv.w};
+          acc1[1][j] = acc1[0][j];
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const int chunk = 8 * (ks >> 1) + 2 * hq + (ks & 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bf16x8 w = *(const bf16x8*)(s1 + (64 * sb + rq + 4 * j) * 256 + ((chunk ^ kq) << 4));
+          acc1[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[0][ks], acc1[0][j], 0, 0, 0);
+          acc1[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[1][ks], acc1[1][j], 0, 0, 0);
+        }
+      }
+      bf16x8 sf[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++) {
+          union { bf16x8 vv; uint32_t u[4]; } cv;
+          const f32x4 a = acc1[mt][2 * sx], b = acc1[mt][2 * sx + 1];
+          cv.u[0] = pack_bf16x2(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)); cv.u[1] = pack_bf16x2(fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+          cv.u[2] = pack_bf16x2(fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)); cv.u[3] = pack_bf16x2(fmaxf(b[2], 0.f), fmaxf(b[3], 0.f));
+          sf[mt][sx] = cv.vv;
+        }
+#pragma unroll
+      for (int sx = 0; sx < 2; sx++) {
+        const int chunk = 8 * sb + 2 * hq + sx;
+#pragma unroll
+        for (int jo = 0; jo < 8; jo++) {
+          const bf16x8 w = *(const bf16x8*)(s2 + (64 * (jo >> 2) + rq + 4 * (jo & 3)) * 256 + ((chunk ^ kq) << 4));
+          acc2[0][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[0][sx], acc2[0][jo], 0, 0, 0);
+          acc2[1][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[1][sx], acc2[1][jo], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: h[tok][64 ob + 16 hq + 4 jp + reg] += acc2 + b2 ----
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int tok = tok0 + mt * 16 + l15;
+    if (tok >= n_tok) continue;
+#pragma unroll
+    for (int ob = 0; ob < 2; ob++) {
+      float4* hp = (float4*)(h + (long)tok * 128 + 64 * ob + 16 * hq);
+      const float4* bp = (const float4*)(b2 + 64 * ob + 16 * hq);
+#pragma unroll
+      for (int jp = 0; jp < 4; jp++) {
+        const float4 r = hp[jp], bv = bp[jp];
+        const f32x4 a = acc2[mt][4 * ob + jp];
+        hp[jp] = make_float4(a[0] + bv.x + r.x, a[1] + bv.y + r.y, a[2] + bv.z + r.z, a[3] + bv.w + r.w);
+      }
+    }
+  }
+}
+
 // chunk means: mem[chunk][:] = mean over the chunk's 150 tokens
 __global__ __launch_bounds__(128) void sep_chunk_mean_kernel(const float* __restrict__ x, float* __restrict__ mem, int seg) {
   const int chunk = blockIdx.x, c = threadIdx.x;
@@ -340,7 +524,7 @@ struct ccx_sepformer {
   // workspaces
   float *feats = nullptr, *x = nullptr, *xin = nullptr, *h = nullptr, *fc = nullptr, *memx = nullptr, *memxin = nullptr,
         *memh = nullptr, *hc = nullptr;
-  bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr, *ffn = nullptr;
+  bf16_t *xn = nullptr, *qkv = nullptr, *att = nullptr;
   int *tok_utt = nullptr, *tok_pos = nullptr, *tok_chunk = nullptr, *tok_cpos = nullptr, *chunk_start = nullptr,
       *chunk_len = nullptr, *utt_L = nullptr, *utt_T = nullptr, *utt_tok0 = nullptr, *utt_chunk0 = nullptr, *utt_nchunk = nullptr,
       *mem_utt = nullptr, *mem_pos = nullptr;
@@ -440,13 +624,18 @@ int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* 
     memset(&p, 0, sizeof(p));
     p.A = s->att; p.lda = D; p.W = L.Wo; p.ldw = D; p.M = n_tok; p.N = D; p.K = D; p.bias = L.bo; p.out = h; p.ldo = D; p.resid = h; p.ldr = D;
     STRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st));
-    STRY(ccx_launch_layernorm(ctx, h, D, L.ln2_g, L.ln2_b, s->xn, nullptr, D, n_tok, D, 1e-6f, st));
-    memset(&p, 0, sizeof(p));
-    p.A = s->xn; p.lda = D; p.W = L.W1; p.ldw = D; p.M = n_tok; p.N = F; p.K = D; p.bias = L.b1; p.out = s->ffn; p.ldo = F;
-    STRY(ccx_launch_gemm(ctx, EPI_BF16_RELU, p, st));
-    memset(&p, 0, sizeof(p));
-    p.A = s->ffn; p.lda = F; p.W = L.W2; p.ldw = F; p.M = n_tok; p.N = D; p.K = F; p.bias = L.b2; p.out = h; p.ldo = D; p.resid = h; p.ldr = D;
-    STRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st));
+    {
+      // LayerNorm 2 + Linear-ReLU-Linear + residual in one kernel (see sep_ffn_kernel)
+      static bool attr_set = false;
+      if (!attr_set) {
+        CCX_HIP(ctx, hipFuncSetAttribute((const void*)sep_ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FF_STAGE));
+        attr_set = true;
+      }
+      ccx_prof_scope ps(ctx, st, "sep_ffn_kernel", 4.0 * n_tok * (double)D * F, 2.0 * n_tok * D * 4.0 + 4.0 * D * F);
+      hipLaunchKernelGGL(sep_ffn_kernel, dim3(ccx_cdiv(n_tok, FF_TOK)), dim3(512), 2 * FF_STAGE, st, h, L.ln2_g, L.ln2_b, L.W1, L.b1, L.W2, L.b2,
+                         n_tok, F, 1e-6f);
+    }
+    CCX_CHECK_LAUNCH(ctx);
   }
   hipLaunchKernelGGL(sep_final_norm_kernel, dim3(n_seq), dim3(256), 0, st, h, xin, seq_start, seq_len, B.lnf_g, B.lnf_b, B.gln_g,
                      B.gln_b, y);
@@ -533,7 +722,7 @@ int ccx_sepformer_finalize(ccx_sepformer* s) {
   const size_t T = (size_t)s->max_tokens;
   STRY(salloc(s, &s->feats, T * D)); STRY(salloc(s, &s->x, T * D)); STRY(salloc(s, &s->xin, T * D)); STRY(salloc(s, &s->h, T * D));
   STRY(salloc(s, &s->fc, T * 2 * D)); STRY(salloc(s, &s->xn, T * D)); STRY(salloc(s, &s->qkv, T * 3 * D));
-  STRY(salloc(s, &s->att, T * D)); STRY(salloc(s, &s->ffn, T * F));
+  STRY(salloc(s, &s->att, T * D));
   STRY(salloc(s, &s->memx, (size_t)max_chunks * D)); STRY(salloc(s, &s->memxin, (size_t)max_chunks * D));
   STRY(salloc(s, &s->memh, (size_t)max_chunks * D)); STRY(salloc(s, &s->hc, (size_t)max_chunks * D));
   STRY(salloc(s, &s->tok_utt, T)); STRY(salloc(s, &s->tok_pos, T)); STRY(salloc(s, &s->tok_chunk, T)); STRY(salloc(s, &s->tok_cpos, T));

@@ -22,7 +22,7 @@ def report(pr, title, n=28):
 
 
 if mode == "stages":
-    models = load_models(None, 0, whisper_batch=8, ctx=ctx, seed=0)
+    models = load_models(None, 0, whisper_batch=8, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32)
     items = [{"waveform": torch.from_numpy(c).cuda(), "sample_rate": 16000} for c in clips]
     for name in ("vad_pipeline", "diarization"):
         kw = dict(min_speakers=1, max_speakers=2) if name == "diarization" else {}
