@@ -115,6 +115,46 @@ def aggregate(chunks: Sequence[np.ndarray], starts: Sequence[int], n_samples: in
     return (acc / np.maximum(cnt, 1)).astype(np.float32)
 
 
+def aggregate_cm(cm: np.ndarray, starts: Sequence[int], n_samples: int) -> np.ndarray:
+    """`aggregate` for equal-sized windows held class-major: cm [C, windows, frames] -> [n_out, C].  Same accumulation
+    order and precision as `aggregate`; the class axis is outermost so every slice added is contiguous (reductions
+    and slices along a trailing axis of 3 or 7 entries are what numpy is slowest at)."""
+    C, _, F = cm.shape
+    n_out = int(np.ceil(n_samples / 270)) + 1
+    acc = np.zeros((C, n_out), dtype=np.float64)
+    cnt = np.zeros(n_out, dtype=np.float64)
+    for w, s0 in enumerate(starts):
+        f0 = int(round(s0 / 270))
+        f1 = min(n_out, f0 + F)
+        acc[:, f0:f1] += cm[:, w, : f1 - f0]
+        cnt[f0:f1] += 1
+    return np.ascontiguousarray((acc / np.maximum(cnt, 1)).T.astype(np.float32))
+
+
+def _powerset_table(n_spk: int = 3, max_set: int = 2) -> np.ndarray:
+    import itertools
+    sets: List[Tuple[int, ...]] = [()]
+    for k in range(1, max_set + 1):
+        sets += list(itertools.combinations(range(n_spk), k))
+    table = np.zeros((len(sets), n_spk), dtype=np.float32)
+    for i, st in enumerate(sets):
+        table[i, list(st)] = 1.0
+    return table
+
+
+_POWERSET_T = np.ascontiguousarray(_powerset_table().T)      # [speaker, class]
+
+
+def multilabel_cm(arr: np.ndarray, powerset: bool) -> np.ndarray:
+    """[windows, frames, classes] scores -> hard multi-label activity, class-major [speakers, windows, frames] float32
+    (powerset: argmax class -> its speaker set, as `powerset_to_multilabel`; multi-label: score > 0.5)."""
+    cm = np.ascontiguousarray(np.moveaxis(arr, -1, 0))
+    if not powerset:
+        return (cm > 0.5).astype(np.float32)
+    idx = np.argmax(cm, axis=0)                                  # reduction over the OUTER axis: vectorised over frames
+    return np.stack([np.take(_POWERSET_T[sp], idx) for sp in range(_POWERSET_T.shape[0])])
+
+
 def binarize(score: np.ndarray, onset: float, offset: float, min_on: float = 0.0, min_off: float = 0.0,
              frame_step: float = FRAME_STEP, t0: float = 0.5 * FRAME_DUR) -> List[Tuple[float, float]]:
     """Hysteresis thresholding of a 1-D frame score (pyannote Binarize): on above `onset`, off below `offset`;
@@ -176,9 +216,15 @@ class VoiceActivityDetection:
 
     def _score(self, outs, starts, n):
         if len({o.shape for o in outs}) == 1:
-            outs = np.stack(outs)               # equal windows: one vectorised reduction for all of them
-            sc = 1.0 - np.exp(outs[..., :1]) if self.net.powerset else outs.max(axis=-1, keepdims=True)
-        elif self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
+            outs = np.stack(outs)               # equal windows: class-major, one contiguous add per window
+            if self.net.powerset:
+                sc = 1.0 - np.exp(outs[..., 0])
+            else:
+                sc = outs[..., 0]
+                for c in range(1, outs.shape[-1]):
+                    sc = np.maximum(sc, outs[..., c])
+            return aggregate_cm(sc[None], starts, n)[:, 0]
+        if self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
             sc = [1.0 - np.exp(o[:, :1]) for o in outs]
         else:
             sc = [o.max(axis=-1, keepdims=True) for o in outs]
@@ -310,31 +356,28 @@ class SpeakerDiarization:
                 continue
             starts, i0, n = pl
             arr = np.stack(seg[i0:i0 + n])                                   # [windows, frames, classes]: windows are equal-sized
-            multi_all = powerset_to_multilabel(arr) if self.net.powerset else (arr > 0.5).astype(np.float32)
-            multi = list(multi_all)
-            act = multi_all > 0                                              # [windows, frames, speakers]
-            alone = multi_all.sum(axis=-1) == 1
-            clean = act & alone[..., None]
-            n_act, n_clean = act.sum(axis=1), clean.sum(axis=1)
-            keep = act.mean(axis=1) >= self.min_active                       # local speakers active for >= min_active_ratio
+            mc = multilabel_cm(arr, self.net.powerset)                       # [speakers, windows, frames] float32 0/1
+            n_spk = mc.sum(axis=0)                                           # active speakers per frame
+            alone = n_spk == 1
+            cleanf = mc * alone                                              # overlap-free activity
+            n_act, n_clean = mc.sum(axis=-1), cleanf.sum(axis=-1)            # [speakers, windows] frame counts (exact in fp32)
+            keep = n_act.astype(np.float64) / mc.shape[-1] >= self.min_active  # local speakers active for >= min_active_ratio
             use_clean = n_clean >= 0.5 * n_act                               # prefer overlap-free frames when enough remain
-            keys = []
-            for ci, sp in zip(*np.nonzero(keep)):                            # row-major: window, then speaker
-                ci, sp = int(ci), int(sp)
-                w = clean[ci, :, sp] if use_clean[ci, sp] else act[ci, :, sp]
-                keys.append((ci, sp))
-                e_crops.append(i0 + ci)
-                e_weights.append(torch.from_numpy(w.astype(np.float32)))
-            per_item.append((starts, multi, keys, list(multi_all.sum(axis=-1, keepdims=True))))   # + active speakers per frame
+            kw, ks = np.nonzero(keep.T)                                      # row-major: window, then speaker
+            keys = list(zip(kw.tolist(), ks.tolist()))
+            e_crops += (i0 + kw).tolist()
+            if len(keys):
+                e_weights.append(np.where(use_clean[ks, kw][:, None], cleanf[ks, kw], mc[ks, kw]))   # [keys, frames] pooling masks
+            per_item.append((starts, mc, keys, n_spk))
         if not e_crops:
             embs = None
         elif hasattr(self.emb, "embed_chunks"):
             # chunk-level embedder (WeSpeaker ResNet-34): the trunk runs once per window, pooling once per local speaker
             used = sorted(set(e_crops))
             where = {g: k for k, g in enumerate(used)}
-            embs = self.emb.embed_chunks(torch.stack([crops[g] for g in used]), torch.stack(e_weights), [where[g] for g in e_crops])
+            embs = self.emb.embed_chunks(torch.stack([crops[g] for g in used]), torch.from_numpy(np.concatenate(e_weights)), [where[g] for g in e_crops])
         else:
-            embs = self.emb.embed_batch([crops[g] for g in e_crops], weights=e_weights)
+            embs = self.emb.embed_batch([crops[g] for g in e_crops], weights=list(torch.from_numpy(np.concatenate(e_weights))))
         return xs, per_item, embs                                            # embs: device tensor, still being computed
 
     def finish(self, handle, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
@@ -348,16 +391,17 @@ class SpeakerDiarization:
             if it is None or not it[2]:
                 anns.append(Annotation([]))
                 continue
-            starts, multi, keys, n_active = it
-            anns.append(self._reconstruct(len(x), starts, multi, keys, embs[e0:e0 + len(keys)], lo, hi, n_active))
+            starts, mc, keys, n_spk = it
+            anns.append(self._reconstruct(len(x), starts, mc, keys, embs[e0:e0 + len(keys)], lo, hi, n_spk))
             e0 += len(keys)
         return anns
 
-    def _reconstruct(self, n_samples: int, starts, multi, keys, embs, lo: int, hi: int, n_active=None) -> Annotation:
+    def _reconstruct(self, n_samples: int, starts, mc, keys, embs, lo: int, hi: int, n_spk=None) -> Annotation:
+        """mc: hard local activity [speakers, windows, frames]; keys: the (window, local speaker) pairs that were embedded."""
         dur = n_samples / SR
-        if n_active is None:
-            n_active = [m.sum(axis=-1, keepdims=True) for m in multi]
-        count = np.rint(aggregate(n_active, starts, n_samples, self.win)[:, 0]).astype(np.int64)
+        if n_spk is None:
+            n_spk = mc.sum(axis=0)
+        count = np.rint(aggregate_cm(n_spk[None], starts, n_samples)[:, 0]).astype(np.int64)
         count = np.minimum(count, hi)
         ok = np.isfinite(embs).all(axis=1)
         labels = np.full(len(keys), -1, dtype=np.int64)
@@ -366,11 +410,11 @@ class SpeakerDiarization:
         n_clusters = int(labels.max()) + 1
         if n_clusters <= 0:
             return Annotation([])
-        clustered = [np.zeros((m.shape[0], n_clusters), dtype=np.float32) for m in multi]
+        clustered = np.zeros((n_clusters,) + mc.shape[1:], dtype=np.float32)
         for (kc, sp), lab in zip(keys, labels):                            # one pass over the (window, local speaker) keys
             if lab >= 0:
-                np.maximum(clustered[kc][:, lab], multi[kc][:, sp], out=clustered[kc][:, lab])
-        agg = aggregate(clustered, starts, n_samples, self.win)          # [frames, clusters]
+                np.maximum(clustered[lab, kc], mc[sp, kc], out=clustered[lab, kc])
+        agg = aggregate_cm(clustered, starts, n_samples)                   # [frames, clusters]
         n_valid = min(agg.shape[0], int(n_samples / 270))
         agg, count = agg[:n_valid], count[:n_valid]
         # to_diarization: at each frame the `count` most active clusters speak

@@ -91,3 +91,34 @@ def test_binarize_vectorised_state_machine_equals_the_loop():
         assert binarize(score, onset, offset, min_on, min_off) == loop(score, onset, offset, min_on, min_off), trial
     assert binarize(np.zeros(0), 0.5, 0.5) == []
     assert binarize(np.array([0.9]), 0.5, 0.4) == []             # a single active frame has zero length
+
+
+def test_host_postnet_matches_fixture():
+    """VAD + diarization host logic over seeded fake networks (tests/fake_nets.py) against the committed fixture:
+    window plans, powerset -> multi-label, pooling-mask choice, clustering, overlap-add, top-`count` selection and
+    binarisation give the same timelines as when the fixture was written (a regression pin of the build's own
+    post-net; the pyannote pipelines themselves are not in the image: parity unpinned)."""
+    import json
+    from tests import fake_nets
+    got = json.loads(json.dumps(fake_nets.run()))
+    with open(fake_nets.GOLDEN) as f:
+        want = json.load(f)
+    assert got == want
+
+
+def test_aggregate_cm_equals_aggregate():
+    rng = np.random.default_rng(5)
+    cm = rng.random((3, 6, 40)).astype(np.float32)
+    starts = [0, 2700, 5400, 8100, 10800, 13500]
+    a = P.aggregate([np.ascontiguousarray(cm[:, w].T) for w in range(6)], starts, 13500 + 40 * 270, 40 * 270)
+    b = P.aggregate_cm(cm, starts, 13500 + 40 * 270)
+    assert np.array_equal(a, b)
+
+
+def test_multilabel_cm_equals_powerset_to_multilabel():
+    rng = np.random.default_rng(6)
+    lp = rng.standard_normal((4, 50, 7)).astype(np.float32)
+    want = np.moveaxis(P.powerset_to_multilabel(lp), -1, 0)
+    assert np.array_equal(P.multilabel_cm(lp, True), want)
+    sc = rng.random((4, 50, 3)).astype(np.float32)
+    assert np.array_equal(P.multilabel_cm(sc, False), np.moveaxis((sc > 0.5).astype(np.float32), -1, 0))
