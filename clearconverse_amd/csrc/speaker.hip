@@ -50,63 +50,97 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float* __restrict_
   }
 }
 
-// Sinc conv (fp32, LDS-staged samples) + abs + maxpool3.  Block = one crop x 32 pooled frames
-// (96 conv frames, 1201 samples in LDS); 320 threads = 80 filters x 4 frame groups (8 pooled frames each).
-// out: [rows][80] f32 pooled |conv|.
-__global__ __launch_bounds__(320) void sinc_conv_pool_kernel(const float* __restrict__ wav, const long* __restrict__ crop_off,
+// ---------------------------------------------------------------------------------------------
+// Sinc convolution (80 filters x 251 taps, stride 10) + |.| + max-pool(3) on the matrix cores with
+// fp32-grade operands: x = xh + xl and w = wh + wl (two bf16 each), out = xh wh + xl wh + xh wl (the
+// dropped xl wl term is 2^-18 relative; bf16 products are exact in the fp32 accumulator).
+//   * k axis: stride 10 divides the taps into groups of 10 consecutive samples; an MFMA step takes 30 taps
+//     = the 30 consecutive samples x[10 p + 30 t ..] of position p (k slots 30, 31 carry zero weights),
+//     9 steps cover taps 0..269 (>= 251: zero weights);
+//   * rows: M tile r (0..2) holds positions 3 i + r of the wave's 16 pooled frames i, so the max-pool is
+//     a max over the three accumulators of a lane;
+//   * a wave = 16 pooled frames x all 80 filters (15 accumulators); the filter fragments (9 steps x 5
+//     tiles x hi/lo, 90 KB) sit lane-linear in LDS for the life of the (persistent) block, the block's
+//     samples are split into hi / lo bf16 arrays once per work item (128 pooled frames).
+// The waveform's instance norm (a x + c) is folded as before: conv(a x + c) = a conv(x) + c sum(w).
+// ---------------------------------------------------------------------------------------------
+#define SM_FRAMES 128
+#define SM_STEPS 9
+#define SM_NS (SM_FRAMES * 3 * SN_STRIDE + 30 * (SM_STEPS - 1) + 32)
+#define SM_BBYTES (SM_STEPS * 5 * 2 * 1024)
+#define SM_LDS (SM_BBYTES + 2 * SM_NS * 2)
+__global__ __launch_bounds__(512) void sinc_conv_pool_kernel(const float* __restrict__ wav, const long* __restrict__ crop_off,
                                                              const int* __restrict__ crop_len, const int* __restrict__ row_off,
                                                              const int* __restrict__ n_pool, const float2* __restrict__ ac,
-                                                             const float* __restrict__ filt_t,   // [251][80]
+                                                             const bf16_t* __restrict__ bfrag,   // [9][5][hi|lo][64 lanes][8]
                                                              const float* __restrict__ filt_sum, // [80]
-                                                             float* __restrict__ out) {
-  // 64 pooled frames (192 conv positions) per block; a thread owns 4 filters x 12 positions, so one tap costs it
-  // 12 LDS reads + one float4 of weights for 48 FMAs (the 1 x 24 blocking was LDS-issue-bound: 25 loads per 24 FMAs)
-  __shared__ float xs[192 * SN_STRIDE + SN_K + 5];
-  const int crop = blockIdx.y, p0 = blockIdx.x * 64;
-  const int np = n_pool[crop];
-  if (p0 >= np) return;
-  const float* x = wav + crop_off[crop];
-  const int n = crop_len[crop];
-  const int s0 = p0 * 3 * SN_STRIDE;
-  for (int i = threadIdx.x; i < 192 * SN_STRIDE + SN_K; i += 320) xs[i] = (s0 + i < n) ? x[s0 + i] : 0.f;
-  __syncthreads();
-  const int f4 = threadIdx.x % 20, grp = threadIdx.x / 20;   // filters 4*f4..+3; pooled frames p0 + 4*grp .. +3
-  // accumulators as pairs of adjacent FILTERS (acc[i2][j] = filters 4 f4 + 2 i2, +1 at position j): w.xy / w.zw are
-  // register pairs already, the sample is broadcast, so every update is one v_pk_fma_f32 (2 FMAs per issue slot)
-  typedef __attribute__((ext_vector_type(2))) float f2;
-  f2 acc[2][12];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 12; j++) acc[i][j] = (f2){0.f, 0.f};
-  const float* xb = xs + grp * 12 * SN_STRIDE;
-  for (int k = 0; k < SN_K; k++) {
-    const float4 w = *(const float4*)(filt_t + k * SN_F + 4 * f4);
-    const f2 w01 = (f2){w.x, w.y}, w23 = (f2){w.z, w.w};
-#pragma unroll
-    for (int j = 0; j < 12; j++) {
-      // op_sel_hi:[1,0,1]: the high lane of the packed op reads the LOW half of the sample operand (broadcast); the
-      // compiler emits only half of these updates as v_pk_fma_f32 on its own
-      f2 xx;
-      xx.x = xb[j * SN_STRIDE + k];
-      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[0][j]) : "v"(w01), "v"(xx));
-      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[1][j]) : "v"(w23), "v"(xx));
+                                                             float* __restrict__ out, int n_crops, int chunks_per_crop) {
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  bf16_t* Bs = (bf16_t*)sm_raw;
+  bf16_t* xh = (bf16_t*)(sm_raw + SM_BBYTES);
+  bf16_t* xl = xh + SM_NS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, hq = lane >> 4;
+  for (int i = tid; i < SM_BBYTES / 16; i += 512) ((uint4*)Bs)[i] = ((const uint4*)bfrag)[i];
+  const int n_items = n_crops * chunks_per_crop;
+  const int abase = 3 * SN_STRIDE * (16 * wave + l15) + 8 * hq;    // + 10 r + 30 t  (bf16 elements, even)
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int crop = item / chunks_per_crop, p0 = (item - crop * chunks_per_crop) * SM_FRAMES;
+    const int np = n_pool[crop];
+    if (p0 >= np) continue;                                         // uniform over the block
+    const float* x = wav + crop_off[crop];
+    const int n = crop_len[crop], s0 = p0 * 3 * SN_STRIDE;
+    __syncthreads();                                                // the previous item's fragment reads are done
+    for (int i = tid; i < SM_NS; i += 512) {
+      const float v = (s0 + i < n) ? x[s0 + i] : 0.f;
+      const bf16_t h = f32_to_bf16(v);
+      xh[i] = h;
+      xl[i] = f32_to_bf16(v - bf16_to_f32(h));
     }
-  }
-  const float2 a_c = ac[crop];
+    __syncthreads();
+    f32x4 acc[3][5];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int p = p0 + 4 * grp + j;
-    if (p < np) {
-      float o[4];
+    for (int r = 0; r < 3; r++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float cs = a_c.y * filt_sum[4 * f4 + i];
-        const float v0 = fabsf(a_c.x * acc[i >> 1][3 * j][i & 1] + cs), v1 = fabsf(a_c.x * acc[i >> 1][3 * j + 1][i & 1] + cs),
-                    v2 = fabsf(a_c.x * acc[i >> 1][3 * j + 2][i & 1] + cs);
-        o[i] = fmaxf(v0, fmaxf(v1, v2));
+      for (int nt = 0; nt < 5; nt++) acc[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t = 0; t < SM_STEPS; t++) {
+      bf16x8 ah[3], al[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const uint32_t* ph = (const uint32_t*)(xh + abase + SN_STRIDE * r + 30 * t);   // 4-byte aligned: ds_read2_b32
+        const uint32_t* pl = (const uint32_t*)(xl + abase + SN_STRIDE * r + 30 * t);
+        union { bf16x8 v; uint32_t u[4]; } ch, cl;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { ch.u[e] = ph[e]; cl.u[e] = pl[e]; }
+        ah[r] = ch.v; al[r] = cl.v;
       }
-      *(float4*)(out + ((long)row_off[crop] + p) * SN_F + 4 * f4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int nt = 0; nt < 5; nt++) {
+        const bf16x8 bh = *(const bf16x8*)(Bs + (((t * 5 + nt) * 2 + 0) * 64 + lane) * 8);
+        const bf16x8 bl = *(const bf16x8*)(Bs + (((t * 5 + nt) * 2 + 1) * 64 + lane) * 8);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh, acc[r][nt], 0, 0, 0);
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl, acc[r][nt], 0, 0, 0);
+          acc[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh, acc[r][nt], 0, 0, 0);
+        }
+      }
+    }
+    const float2 a_c = ac[crop];
+    const long orow = (long)row_off[crop] + p0 + 16 * wave + 4 * hq;
+#pragma unroll
+    for (int nt = 0; nt < 5; nt++) {
+      const int f = 16 * nt + l15;
+      const float cs = a_c.y * filt_sum[f];
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        if (p0 + 16 * wave + 4 * hq + reg < np) {
+          const float v0 = fabsf(fmaf(a_c.x, acc[0][nt][reg], cs)), v1 = fabsf(fmaf(a_c.x, acc[1][nt][reg], cs)),
+                      v2 = fabsf(fmaf(a_c.x, acc[2][nt][reg], cs));
+          out[(orow + reg) * SN_F + f] = fmaxf(v0, fmaxf(v1, v2));
+        }
+      }
     }
   }
 }
@@ -378,7 +412,8 @@ inline bf16_t h2bf(float f) {
 }
 
 struct SincNetW {
-  float *nw, *nb, *filt_t, *filt_sum, *n0g, *n0b, *n1g, *n1b, *n2g, *n2b, *b1, *b2;
+  float *nw, *nb, *filt_sum, *n0g, *n0b, *n1g, *n1b, *n2g, *n2b, *b1, *b2;
+  bf16_t* bfrag;    // sinc filters as MFMA B fragments [9 steps][5 tiles][hi|lo][64 lanes][8]
   bf16_t *W1, *W2;  // conv k5: [60][448] (5 x 80 padded) and [60][320] (5 x 64)
 };
 
@@ -487,11 +522,22 @@ int load_sincnet(ccx_speaker* s, const std::string& pre) {
   PNEED(g0, pre + "norm1d.0.weight", 80); PNEED(be0, pre + "norm1d.0.bias", 80);
   PNEED(g1, pre + "norm1d.1.weight", 60); PNEED(be1, pre + "norm1d.1.bias", 60);
   PNEED(g2, pre + "norm1d.2.weight", 60); PNEED(be2, pre + "norm1d.2.bias", 60);
-  std::vector<float> ft((size_t)SN_K * SN_F), fs(SN_F, 0.f);
+  std::vector<float> fs(SN_F, 0.f), frag((size_t)SM_STEPS * 5 * 2 * 64 * 8, 0.f);
   for (int f = 0; f < SN_F; f++)
-    for (int k = 0; k < SN_K; k++) { ft[(size_t)k * SN_F + f] = fl->data[(size_t)f * SN_K + k]; fs[f] += fl->data[(size_t)f * SN_K + k]; }
+    for (int k = 0; k < SN_K; k++) fs[f] += fl->data[(size_t)f * SN_K + k];
+  for (int t = 0; t < SM_STEPS; t++)
+    for (int nt = 0; nt < 5; nt++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int e = 0; e < 8; e++) {
+          const int kk = 8 * (lane >> 4) + e, tap = 30 * t + kk, f = 16 * nt + (lane & 15);
+          const float w = (kk < 30 && tap < SN_K) ? fl->data[(size_t)f * SN_K + tap] : 0.f;
+          const bf16_t hb = h2bf(w);
+          uint32_t hu = (uint32_t)hb << 16; float hf; memcpy(&hf, &hu, 4);
+          frag[((((size_t)t * 5 + nt) * 2 + 0) * 64 + lane) * 8 + e] = hf;       // exactly representable: pup_bf16 keeps it
+          frag[((((size_t)t * 5 + nt) * 2 + 1) * 64 + lane) * 8 + e] = w - hf;   // rounded to bf16 by pup_bf16
+        }
   PTRY(pup_f32(s, &n.nw, nw->data.data(), 1)); PTRY(pup_f32(s, &n.nb, nb->data.data(), 1));
-  PTRY(pup_f32(s, &n.filt_t, ft.data(), ft.size())); PTRY(pup_f32(s, &n.filt_sum, fs.data(), fs.size()));
+  PTRY(pup_bf16(s, &n.bfrag, frag)); PTRY(pup_f32(s, &n.filt_sum, fs.data(), fs.size()));
   PTRY(pup_bf16(s, &n.W1, conv_w(w1->data, 60, 80, 5, 80, 448))); PTRY(pup_f32(s, &n.b1, b1->data.data(), 60));
   PTRY(pup_bf16(s, &n.W2, conv_w(w2->data, 60, 60, 5, 64, 320))); PTRY(pup_f32(s, &n.b2, b2->data.data(), 60));
   PTRY(pup_f32(s, &n.n0g, g0->data.data(), 80)); PTRY(pup_f32(s, &n.n0b, be0->data.data(), 80));
@@ -538,9 +584,18 @@ int run_sincnet(ccx_speaker* s, const float* wav, const Plan& P, hipStream_t st)
   int maxp = 0;
   for (int i = 0; i < P.n; i++) maxp = P.f1[i] > maxp ? P.f1[i] : maxp;
   {
-    ccx_prof_scope ps(ctx, st, "sinc_conv_pool_kernel", 0.0, 0.0);
-    hipLaunchKernelGGL(sinc_conv_pool_kernel, dim3(ccx_cdiv(maxp, 64), P.n), dim3(320), 0, st, wav, s->crop_off, s->crop_len, s->off1,
-                       s->nF1, s->ac, n.filt_t, n.filt_sum, s->s1);
+    static bool attr_set = false;
+    if (!attr_set) {
+      CCX_HIP(ctx, hipFuncSetAttribute((const void*)sinc_conv_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS));
+      attr_set = true;
+    }
+    const int chunks = ccx_cdiv(maxp, SM_FRAMES);
+    const long items = (long)chunks * P.n;
+    long positions = 0;
+    for (int i = 0; i < P.n; i++) positions += 3L * P.f1[i];
+    ccx_prof_scope ps(ctx, st, "sinc_conv_pool_kernel", 2.0 * positions * SN_F * SN_K, 0.0);
+    hipLaunchKernelGGL(sinc_conv_pool_kernel, dim3((unsigned)(items < 256 ? items : 256)), dim3(512), SM_LDS, st, wav, s->crop_off, s->crop_len,
+                       s->off1, s->nF1, s->ac, n.bfrag, n.filt_sum, s->s1, P.n, chunks);
   }
   CCX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(inorm_partial_kernel<1>, dim3(P.n, INORM_CHUNKS, 2), dim3(256), 0, st, s->s1, 80, s->off1, s->nF1, s->inorm_part, 80, 128);
