@@ -12,6 +12,7 @@
 // QKV GEMM epilogue, so both LDS operands are plain ds_read_b128 row reads.
 // K / V^T tiles stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered,
 // XOR-swizzled on the source address (key (row>>1)&7, conflict-free per tools/lds_bank_sim.py).
+#include <type_traits>
 #include "attention.h"
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -77,36 +78,35 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
   float m_run = -1e30f, l_run = 0.f;
 
   const int nT = (S + 63) >> 6;
-  stage(0, 0);
-  __syncthreads();
-  for (int t = 0; t < nT; t++) {
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // One K/V tile.  TAIL (only the last tile can be ragged) is a compile-time tag: the key-range masking costs two VALU
+  // slots per score when it sits in the common path.
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1;
     if (t + 1 < nT) stage(t + 1, buf ^ 1);
     const char* sK = smem + buf * ATT_STAGE;
     const char* sV = sK + 8192;
 
-    // ---- S^T = K * Q^T : two 32-key sub-tiles ----
+    // ---- S^T = K * Q^T : two 32-key sub-tiles (the first MFMA of a chain takes the constant 0 as its accumulator) ----
     f32x16 sT[2];
 #pragma unroll
     for (int kt = 0; kt < 2; kt++) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) sT[kt][i] = 0.f;
-#pragma unroll
       for (int ds = 0; ds < 4; ds++) {
         const bf16x8 kf = *(const bf16x8*)(sK + kt * 32 * 128 + offK[ds]);
-        sT[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sT[kt], 0, 0, 0);
+        sT[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], ds == 0 ? zero16 : sT[kt], 0, 0, 0);
       }
     }
     // reg r of sub-tile kt <-> key t*64 + kt*32 + 16*(r>>3) + 8*hh + (r&7)
     // softmax in the exp2 domain with the scale folded into ONE fma per score: p = exp2(s * c - m * c), c = scale * log2(e).
     // (The kernel is VALU-bound at d = 64: every issue slot saved per score is MFMA time regained.)  m_run is kept scaled.
     float mx = -1e30f;
-    const bool tail = (t * 64 + 64 > S);
 #pragma unroll
     for (int kt = 0; kt < 2; kt++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        if (tail) {
+        if (TAIL) {
           const int key = t * 64 + kt * 32 + 16 * (r >> 3) + 8 * hh + (r & 7);
           if (key >= S) sT[kt][r] = -INFINITY;
         }
@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
         psum += pv;
       }
     l_run = l_run * alpha + psum;
+    // the running maximum settles after the first tiles: skip the 32 rescaling multiplies when no lane of the wave moved
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+      for (int i = 0; i < 16; i++) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+    }
 
     // ---- P^T fragments straight from the accumulators (B operand, 16 keys per k-step) ----
     bf16x8 pf[4];
@@ -149,7 +152,12 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
         oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], oT[dt], 0, 0, 0);
       }
     __syncthreads();
-  }
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nT - 1; t++) tile(t, std::false_type{});
+  if ((S & 63) != 0) tile(nT - 1, std::true_type{});
+  else tile(nT - 1, std::false_type{});
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;

@@ -90,8 +90,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(uint16_t, b);
 }
 
+// two round-to-nearest-even conversions in ONE v_cvt_pk_bf16_f32 (the scalar form costs a convert, a shift and an or per value)
+typedef __attribute__((ext_vector_type(2))) float ccx_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 ccx_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const ccx_bf16x2 v = __builtin_convertvector((ccx_f32x2){lo, hi}, ccx_bf16x2);
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
