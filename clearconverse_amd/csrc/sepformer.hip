@@ -74,7 +74,7 @@ __global__ void sep_block_input_kernel(const float* __restrict__ x, const float*
 // k = key), so P never leaves registers.  V is read as B operand (k = key, col = d).
 // qkv: [n_tok, 384] bf16 (q | k | v, heads contiguous inside each 128).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sep_attention_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ seq_start,
+__global__ __launch_bounds__(256, 2) void sep_attention_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ seq_start,
                                                             const int* __restrict__ seq_len, bf16_t* __restrict__ out,
                                                             float scale_log2e) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
