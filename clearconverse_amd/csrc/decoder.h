@@ -39,6 +39,7 @@ struct DecAttnParams {
   bf16_t* out_bf16;     // FINAL: [B][H*64]
   float* part_o;        // partials [B][H][nsplit][64]
   float* part_ml;       // [B][H][nsplit][2]
+  int lds_pad;          // dynamic LDS the blocks claim without using it: caps the blocks per CU (see ccx_whisper_decode)
 };
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out, hipStream_t stream);
 

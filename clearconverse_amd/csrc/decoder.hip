@@ -645,7 +645,14 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
     ccx_prof_scope ps(ctx, stream, final_out ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
                       (double)B * p.H * keys * 64 * 2 * 2);
     if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), 0, stream, p);
+    else {
+      static bool attr_set = false;
+      if (p.lds_pad > 0 && !attr_set) {   // static + dynamic LDS beyond 64 KB needs the opt-in
+        CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0, stream, p);
+    }
   }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;

@@ -116,6 +116,7 @@ struct ccx_whisper {
   // that one lane's HBM-bound cross attention overlaps the other lanes' latency-bound linears.  The gain is
   // modest (3-4 % at 192 sequences): the small kernels slow down 3-5x while HBM is saturated by another lane.
   static constexpr int kMaxLanes = 4;
+  int cross_lds_pad = 0;                     // see ccx_whisper_decode: occupancy cap of the cross-attention blocks while lanes overlap
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
                                              // queue run strictly one after the other, so lanes are picked by a probe
@@ -777,6 +778,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     memset(&ap, 0, sizeof(ap));
     ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
+    ap.lds_pad = w->cross_lds_pad;
     if (B > 16) {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
       if (ns > 1) TRY(ccx_launch_dec_combine(ctx, part_o, part_ml, ns, dattn, B, H, stream));
@@ -923,6 +925,14 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   if (nl > 1) {
     extra = &lane_streams_for(w, stream, nl - 1);
     if ((int)extra->size() + 1 < nl) nl = (int)extra->size() + 1;
+  }
+  // While lanes overlap, the cross attention of one lane (4,608 short blocks that fill every wave slot) makes the other
+  // lanes' 5-8 us kernels queue for a slot.  Its blocks therefore claim 64 KB of LDS they do not use: two blocks per CU
+  // still keep HBM saturated (each wave has 16 KB of loads in flight; 49.4 -> 51.3 us per launch) and the pipeline step
+  // drops 924 -> 897 ms (3 blocks per CU: 910; 4: 919; 1: 979).  CCX_CROSS_LDS_PAD overrides.
+  {
+    static const int forced_pad = [] { const char* e = getenv("CCX_CROSS_LDS_PAD"); return e ? atoi(e) : -1; }();
+    w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? 65536 : 0);
   }
   struct Lane { int b0, B; hipStream_t s; hipGraphExec_t exec; };
   Lane lanes[ccx_whisper::kMaxLanes];
