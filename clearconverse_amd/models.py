@@ -49,7 +49,7 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
 def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
-                seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0) -> Dict[str, object]:
+                seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None) -> Dict[str, object]:
     if not torch.cuda.is_available():
         raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
     dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
@@ -61,7 +61,7 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     sd_ = sep_dims or SepDims()
     separator = SepformerSeparator(sd_, W["sepformer"], max_tokens=sep_tokens, max_utts=64,
                                    device=dev_index, ctx=ctx)
-    embedder = XVectorEmbedder(W["xvector"], max_crops=max_crops, max_samples=16000 * 1200,
+    embedder = XVectorEmbedder(W["xvector"], max_crops=int(emb_max_crops or max_crops), max_samples=16000 * 1200,
                                device=dev_index, ctx=ctx)
     # embedding model of the diarization pipeline (speaker-diarization-3.1 uses WeSpeaker ResNet-34, not pyannote/embedding)
     diar_embedder = ResNetEmbedder(W["resnet34"], max_chunks=96, max_samples=160000, max_masks=512,
