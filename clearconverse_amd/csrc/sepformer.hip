@@ -263,47 +263,53 @@ __global__ __launch_bounds__(256) void sep_final_norm_kernel(const float* __rest
 //     (64 ob + 16 hq + 0..15), so the epilogue adds bias and the residual row 64 B at a time.
 // ---------------------------------------------------------------------------------------------
 #define FF_TOK 256
-#define FF_HB 128
-#define FF_PART (FF_HB * 256)
-#define FF_STAGE (2 * FF_PART)
+#define FF_HB 64                        // hidden units per stage
+#define FF_P1 (FF_HB * 256)             // W1 part: HB rows x 128 features (256-byte rows, 16 chunks)   16 KB
+#define FF_P2 (128 * FF_HB * 2)         // W2 part: 128 rows x HB hidden (128-byte rows, 8 chunks)     16 KB
+#define FF_STAGE (FF_P1 + FF_P2)
+#define FF_NSTAGE 4                     // LDS ring: stages st+1 .. st+2 stay in flight while stage st is consumed
+#define FF_LDS (FF_NSTAGE * FF_STAGE + 4096)
 typedef const __attribute__((address_space(1))) void* ff_gptr_t;
 typedef __attribute__((address_space(3))) void* ff_lptr_t;
 
-__device__ __forceinline__ int ff_key(int r) { return (r & 3) | (((r >> 4) & 3) << 2); }
+__device__ __forceinline__ int ff_key1(int r) { return (r & 3) | (((r >> 4) & 3) << 2); }          // 256-byte rows
+__device__ __forceinline__ int ff_key2(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }   // 128-byte rows
 
 __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                       const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                       const bf16_t* __restrict__ W2, const float* __restrict__ b2, int n_tok, int d_ffn,
                                                       float eps) {
-  extern __shared__ __attribute__((aligned(16))) char ff_smem[];
+  extern __shared__ __attribute__((aligned(16))) char ff_smem[];   // ring of FF_NSTAGE stages, then b1 (<= 1024 floats)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, hq = lane >> 4;
   const int tok0 = blockIdx.x * FF_TOK + wave * 32;
   const int n_stage = d_ffn / FF_HB;
+  float* b1s = (float*)(ff_smem + FF_NSTAGE * FF_STAGE);
 
-  // ---- weight staging: DMA instruction i of a part covers its LDS rows 4i .. 4i+3 (256 B each) ----
-  const bf16_t* src1[4];
-  const bf16_t* src2[4];
+  // ---- weight staging: per stage and wave 2 DMA instructions of the W1 part (4 rows of 256 B each) and 2 of the
+  //      W2 part (8 rows of 128 B each); the XOR swizzle is applied to the SOURCE chunk (the LDS image is lane-linear)
+  const bf16_t* src1[2];
+  const bf16_t* src2[2];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int row = (wave * 4 + i) * 4 + (lane >> 4);
-    const int gch = (lane & 15) ^ ff_key(row);
-    src1[i] = W1 + (long)row * 128 + gch * 8;      // + stage * FF_HB rows
-    src2[i] = W2 + (long)row * d_ffn + gch * 8;    // + stage * FF_HB columns
+  for (int i = 0; i < 2; i++) {
+    const int r1 = (wave * 2 + i) * 4 + (lane >> 4);
+    src1[i] = W1 + (long)r1 * 128 + (((lane & 15) ^ ff_key1(r1)) << 3);      // + stage * FF_HB rows
+    const int r2 = (wave * 2 + i) * 8 + (lane >> 3);
+    src2[i] = W2 + (long)r2 * d_ffn + (((lane & 7) ^ ff_key2(r2)) << 3);     // + stage * FF_HB columns
   }
-  auto stage = [&](int st, int buf) {
-    char* s1 = ff_smem + buf * FF_STAGE;
-    char* s2 = s1 + FF_PART;
+  auto stage = [&](int st) {
+    char* s1 = ff_smem + (st & (FF_NSTAGE - 1)) * FF_STAGE;
+    char* s2 = s1 + FF_P1;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src1[i] + (long)st * FF_HB * 128), (ff_lptr_t)(s1 + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src1[i] + (long)st * FF_HB * 128), (ff_lptr_t)(s1 + (wave * 2 + i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src2[i] + (long)st * FF_HB), (ff_lptr_t)(s2 + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < 2; i++)
+      __builtin_amdgcn_global_load_lds((ff_gptr_t)(src2[i] + (long)st * FF_HB), (ff_lptr_t)(s2 + (wave * 2 + i) * 1024), 16, 0, 0);
   };
-  stage(0, 0);
 
   // ---- LayerNorm of the wave's 32 tokens -> bf16 fragments xb[mt][ks] (features 64 (ks>>1) + 16 hq + 8 (ks&1) + 0..7) ----
+  // (ordinary global loads: all of them retire before the first LDS-DMA is issued, see the vmcnt accounting below)
   bf16x8 xb[2][4];
   {
     float g[32], bt[32];
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, con
       }
     }
   }
+  for (int i = tid; i < d_ffn; i += 512) b1s[i] = b1[i];     // b1 through LDS: a VGPR load inside the loop would drain the DMA ring
 
   f32x4 acc2[2][8];
 #pragma unroll
@@ -358,58 +365,71 @@ __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, con
     for (int jo = 0; jo < 8; jo++) acc2[mt][jo] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int rq = 16 * (l15 >> 2) + (l15 & 3);            // permuted operand row inside a 64-row block (+ 4 j)
-  const int kq = (l15 & 3) | ((l15 >> 2) << 2);          // ff_key of that row (independent of j and of the 64-block)
-  __syncthreads();
+  const int k1 = l15;                                    // ff_key1 of that row (u | q << 2), independent of j
+  const int k2 = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);   // ff_key2 of that row
+  // every wave issues the same 4 DMA instructions per stage, in stage order: with stages st+1, st+2 already issued,
+  // vmcnt(8) means "my part of stage st has landed"; the barrier then makes all eight parts visible, and it also
+  // tells that every wave is done reading stage st-1, whose buffer stage st+3 overwrites next.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage(0);
+  if (n_stage > 1) stage(1);
+  if (n_stage > 2) stage(2);
   for (int st = 0; st < n_stage; st++) {
-    const int buf = st & 1;
-    if (st + 1 < n_stage) stage(st + 1, buf ^ 1);
-    const char* s1 = ff_smem + buf * FF_STAGE;
-    const char* s2 = s1 + FF_PART;
+    const int ahead = n_stage - 1 - st;                  // stages issued after st (at most 2 here)
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 3 < n_stage) stage(st + 3);
+    const char* s1 = ff_smem + (st & (FF_NSTAGE - 1)) * FF_STAGE;
+    const char* s2 = s1 + FF_P1;
+    f32x4 acc1[2][4];
+    // bias slice of this stage: inline-asm reads (hipcc would wait vmcnt(0) -- the whole DMA ring -- in front of an
+    // ordinary read of this part of the array); they are waited for after GEMM 1, where their latency is long gone
+    f32x4 bv[4];
+    {
+      const uint32_t baddr = (uint32_t)(uintptr_t)(ff_lptr_t)(b1s + st * FF_HB + 16 * hq);
 #pragma unroll
-    for (int sb = 0; sb < 2; sb++) {
-      f32x4 acc1[2][4];
-      {
-        const float4* bp = (const float4*)(b1 + st * FF_HB + 64 * sb + 16 * hq);
+      for (int j = 0; j < 4; j++) asm volatile("ds_read_b128 %0, %1" : "=v"(bv[j]) : "v"(baddr + 16 * j) : "memory");
+    }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float4 bv = bp[j];
-          acc1[0][j] = (f32x4){bv.x, bv.y, bv.z, bv.w};
-          acc1[1][j] = acc1[0][j];
-        }
-      }
+    for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        const int chunk = 8 * (ks >> 1) + 2 * hq + (ks & 1);
+      for (int j = 0; j < 4; j++) acc1[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const bf16x8 w = *(const bf16x8*)(s1 + (64 * sb + rq + 4 * j) * 256 + ((chunk ^ kq) << 4));
-          acc1[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[0][ks], acc1[0][j], 0, 0, 0);
-          acc1[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[1][ks], acc1[1][j], 0, 0, 0);
-        }
-      }
-      bf16x8 sf[2][2];
+    for (int ks = 0; ks < 4; ks++) {
+      const int chunk = 8 * (ks >> 1) + 2 * hq + (ks & 1);
 #pragma unroll
-      for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int sx = 0; sx < 2; sx++) {
-          union { bf16x8 vv; uint32_t u[4]; } cv;
-          const f32x4 a = acc1[mt][2 * sx], b = acc1[mt][2 * sx + 1];
-          cv.u[0] = pack_bf16x2(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)); cv.u[1] = pack_bf16x2(fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
-          cv.u[2] = pack_bf16x2(fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)); cv.u[3] = pack_bf16x2(fmaxf(b[2], 0.f), fmaxf(b[3], 0.f));
-          sf[mt][sx] = cv.vv;
-        }
-#pragma unroll
-      for (int sx = 0; sx < 2; sx++) {
-        const int chunk = 8 * sb + 2 * hq + sx;
-#pragma unroll
-        for (int jo = 0; jo < 8; jo++) {
-          const bf16x8 w = *(const bf16x8*)(s2 + (64 * (jo >> 2) + rq + 4 * (jo & 3)) * 256 + ((chunk ^ kq) << 4));
-          acc2[0][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[0][sx], acc2[0][jo], 0, 0, 0);
-          acc2[1][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[1][sx], acc2[1][jo], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; j++) {
+        const bf16x8 w = *(const bf16x8*)(s1 + (rq + 4 * j) * 256 + ((chunk ^ k1) << 4));
+        acc1[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[0][ks], acc1[0][j], 0, 0, 0);
+        acc1[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xb[1][ks], acc1[1][j], 0, 0, 0);
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 sf[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int sx = 0; sx < 2; sx++) {
+        union { bf16x8 vv; uint32_t u[4]; } cv;
+        const f32x4 a = acc1[mt][2 * sx] + bv[2 * sx], b = acc1[mt][2 * sx + 1] + bv[2 * sx + 1];
+        cv.u[0] = pack_bf16x2(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)); cv.u[1] = pack_bf16x2(fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+        cv.u[2] = pack_bf16x2(fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)); cv.u[3] = pack_bf16x2(fmaxf(b[2], 0.f), fmaxf(b[3], 0.f));
+        sf[mt][sx] = cv.vv;
+      }
+#pragma unroll
+    for (int sx = 0; sx < 2; sx++) {
+      const int chunk = 2 * hq + sx;
+#pragma unroll
+      for (int jo = 0; jo < 8; jo++) {
+        const bf16x8 w = *(const bf16x8*)(s2 + (64 * (jo >> 2) + rq + 4 * (jo & 3)) * 128 + ((chunk ^ k2) << 4));
+        acc2[0][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[0][sx], acc2[0][jo], 0, 0, 0);
+        acc2[1][jo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, sf[1][sx], acc2[1][jo], 0, 0, 0);
+      }
+    }
   }
 
   // ---- epilogue: h[tok][64 ob + 16 hq + 4 jp + reg] += acc2 + b2 ----
@@ -628,11 +648,11 @@ int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* 
       // LayerNorm 2 + Linear-ReLU-Linear + residual in one kernel (see sep_ffn_kernel)
       static bool attr_set = false;
       if (!attr_set) {
-        CCX_HIP(ctx, hipFuncSetAttribute((const void*)sep_ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FF_STAGE));
+        CCX_HIP(ctx, hipFuncSetAttribute((const void*)sep_ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
         attr_set = true;
       }
       ccx_prof_scope ps(ctx, st, "sep_ffn_kernel", 4.0 * n_tok * (double)D * F, 2.0 * n_tok * D * 4.0 + 4.0 * D * F);
-      hipLaunchKernelGGL(sep_ffn_kernel, dim3(ccx_cdiv(n_tok, FF_TOK)), dim3(512), 2 * FF_STAGE, st, h, L.ln2_g, L.ln2_b, L.W1, L.b1, L.W2, L.b2,
+      hipLaunchKernelGGL(sep_ffn_kernel, dim3(ccx_cdiv(n_tok, FF_TOK)), dim3(512), FF_LDS, st, h, L.ln2_g, L.ln2_b, L.W1, L.b1, L.W2, L.b2,
                          n_tok, F, 1e-6f);
     }
     CCX_CHECK_LAUNCH(ctx);
@@ -653,7 +673,7 @@ int ccx_sepformer_create(ccx_ctx* ctx, const ccx_sepformer_dims* dims, int max_t
   const ccx_sepformer_dims& d = *dims;
   CCX_REQUIRE(ctx, d.n_filters == 128 && d.d_model == 128 && d.kernel == 16 && d.stride == 8 && d.n_head == 8 && d.n_spk == 2,
               "sepformer: only the resepformer-wsj02mix geometry (128 filters, k16 s8, d_model 128, 8 heads, 2 speakers) is built");
-  CCX_REQUIRE(ctx, d.d_ffn % 128 == 0 && d.segment >= 16 && d.n_layers >= 1 && d.n_blocks >= 1, "sepformer: bad dims");
+  CCX_REQUIRE(ctx, d.d_ffn % 128 == 0 && d.d_ffn <= 1024 && d.segment >= 16 && d.n_layers >= 1 && d.n_blocks >= 1, "sepformer: bad dims");
   CCX_REQUIRE(ctx, max_tokens >= d.segment && max_utts >= 1, "sepformer: capacity too small");
   ccx_sepformer* s = new ccx_sepformer();
   s->ctx = ctx; s->d = d;

@@ -101,3 +101,23 @@ def test_rejects_too_short_input(small):
     from clearconverse_amd._lib import CcxError
     with pytest.raises(CcxError):
         m.separate_batch(torch.zeros(1, 8))
+
+
+@pytest.mark.parametrize("d_ffn", [128, 384])
+def test_fused_ffn_other_widths(ccx_ctx, d_ffn):
+    """The fused LayerNorm + FFN kernel streams W1 / W2 in stages of 128 hidden units over two LDS buffers: one stage and
+    an odd number of stages (the default width is 8 stages) against the oracle."""
+    from clearconverse_amd.separator import SepformerSeparator
+    dims = SepDims(n_layers=1, d_ffn=d_ffn)
+    sd = synthetic_sepformer_state_dict(dims, seed=9)
+    m = SepformerSeparator(dims, sd, max_tokens=20000, max_utts=4, ctx=ccx_ctx)
+    try:
+        lengths = [6000, 3111]
+        mix = _mix(lengths)
+        got = m.separate_batch(mix, lengths).cpu()
+        orc = S.SepformerRef(S.SepDims(**dims.__dict__), sd)
+        for i, n in enumerate(lengths):
+            ref = orc.separate(mix[i:i + 1, :n])[0]
+            assert _rel(got[i, :n], ref) < 3e-2, (i, _rel(got[i, :n], ref))
+    finally:
+        m.close()
