@@ -190,26 +190,43 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, hq = lane >> 4;
   const long Wp = W + 2;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, img = blockIdx.z;
+  const int y0 = blockIdx.y * TH, img = blockIdx.z;
   const bf16_t* src = in + ((long)img * (H + 2) + y0) * Wp * 32;
-  // ---- stage the halo tile: 6 rows x 66 pixels x 4 chunks of 16 B; all loads are issued before the first LDS store ----
+  // A block walks its 4-row strip in x tiles of 64 pixels: the weights are fetched once, and the halo tile (and the
+  // residual pixels) of tile k+1 travel HBM -> registers while tile k is multiplied, so only the first tile of a
+  // strip waits for memory (one short-lived block per tile spent most of its life in that wait).
   constexpr int NCH = (TH + 2) * (TW + 2) * 4, NIT = (NCH + 255) / 256;
   uint4 stg[NIT];
+  uint4 rres[4];
+  const long orow = ((long)img * (H + 2) + y0 + wave + 1) * Wp + 1;
+  auto fetch = [&](int x0) {       // 6 rows x 66 pixels x 4 chunks of 16 B
 #pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int idx = tid + 256 * it;
-    const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
-    const int px = rem >> 2, q = rem & 3;
-    stg[it] = make_uint4(0, 0, 0, 0);
-    if (idx < NCH && x0 + px < Wp) stg[it] = *(const uint4*)(src + ((long)row * Wp + x0 + px) * 32 + q * 8);
-  }
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + 256 * it;
+      const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
+      const int px = rem >> 2, q = rem & 3;
+      stg[it] = make_uint4(0, 0, 0, 0);
+      if (idx < NCH && x0 + px < Wp) stg[it] = *(const uint4*)(src + ((long)row * Wp + x0 + px) * 32 + q * 8);
+    }
+    if (HAS_RESID) {
 #pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    const int idx = tid + 256 * it;
-    const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
-    const int px = rem >> 2, q = rem & 3;
-    if (idx < NCH) *(uint4*)(tile + (row * (TW + 2) + px) * PITCH + q * 16) = stg[it];
-  }
+      for (int pt = 0; pt < 4; pt++) {
+        const int x = x0 + pt * 16 + l15;
+        rres[pt] = make_uint4(0, 0, 0, 0);
+        if (x < W) rres[pt] = *(const uint4*)(resid + (orow + x) * 32 + 8 * hq);
+      }
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int idx = tid + 256 * it;
+      const int row = idx / ((TW + 2) * 4), rem = idx - row * (TW + 2) * 4;
+      const int px = rem >> 2, q = rem & 3;
+      if (idx < NCH) *(uint4*)(tile + (row * (TW + 2) + px) * PITCH + q * 16) = stg[it];
+    }
+  };
+  fetch(0);
   // ---- weights: A operand of tap t, channel block j: row i = l15 -> output channel 8 (i >> 2) + 4 j + (i & 3) ----
   bf16x8 wf[9][2];
 #pragma unroll
@@ -222,57 +239,58 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const bf16_t* __restri
   float bv[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) bv[i] = bias[8 * hq + i];
-  // residual of this lane's four pixels: fetched now, used in the epilogue (no dependent load after the MFMAs)
-  const long orow = ((long)img * (H + 2) + y0 + wave + 1) * Wp + 1;
-  uint4 rres[4];
-  if (HAS_RESID) {
+  const int n_tiles = (W + TW - 1) / TW;
+  for (int k = 0; k < n_tiles; k++) {
+    const int x0 = k * TW;
+    put();
+    uint4 rcur[4];
+    if (HAS_RESID) {
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) rcur[pt] = rres[pt];
+    }
+    __syncthreads();
+    if (k + 1 < n_tiles) fetch(x0 + TW);     // in flight during this tile's MFMAs
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int pt = 0; pt < 4; pt++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[pt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int kh = t / 3, kw = t % 3;
+#pragma unroll
+      for (int pt = 0; pt < 4; pt++) {
+        // B operand: column = pixel pt*16 + l15, k-slice hq: 8 input channels of the tap's pixel
+        const bf16x8 bfrag = *(const bf16x8*)(tile + ((wave + kh) * (TW + 2) + pt * 16 + l15 + kw) * PITCH + hq * 16);
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], bfrag, acc[pt][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: lane (pixel l15, quarter hq) holds output channels 8 hq + 4 j + r ----
 #pragma unroll
     for (int pt = 0; pt < 4; pt++) {
       const int x = x0 + pt * 16 + l15;
-      rres[pt] = make_uint4(0, 0, 0, 0);
-      if (x < W) rres[pt] = *(const uint4*)(resid + (orow + x) * 32 + 8 * hq);
-    }
-  }
-  __syncthreads();
-  f32x4 acc[4][2];
+      if (x >= W) continue;
+      float v[8];
 #pragma unroll
-  for (int pt = 0; pt < 4; pt++)
+      for (int j = 0; j < 2; j++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) acc[pt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; r++) v[4 * j + r] = acc[pt][j][r] + bv[4 * j + r];
+      const long off = (orow + x) * 32 + 8 * hq;
+      if (HAS_RESID) {
+        const uint32_t rw[4] = {rcur[pt].x, rcur[pt].y, rcur[pt].z, rcur[pt].w};
 #pragma unroll
-  for (int t = 0; t < 9; t++) {
-    const int kh = t / 3, kw = t % 3;
-#pragma unroll
-    for (int pt = 0; pt < 4; pt++) {
-      // B operand: column = pixel pt*16 + l15, k-slice hq: 8 input channels of the tap's pixel
-      const bf16x8 bfrag = *(const bf16x8*)(tile + ((wave + kh) * (TW + 2) + pt * 16 + l15 + kw) * PITCH + hq * 16);
-#pragma unroll
-      for (int j = 0; j < 2; j++) acc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][j], bfrag, acc[pt][j], 0, 0, 0);
-    }
-  }
-  // ---- epilogue: lane (pixel l15, quarter hq) holds output channels 8 hq + 4 j + r ----
-#pragma unroll
-  for (int pt = 0; pt < 4; pt++) {
-    const int x = x0 + pt * 16 + l15;
-    if (x >= W) continue;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) v[4 * j + r] = acc[pt][j][r] + bv[4 * j + r];
-    const long off = (orow + x) * 32 + 8 * hq;
-    if (HAS_RESID) {
-      const uint32_t rw[4] = {rres[pt].x, rres[pt].y, rres[pt].z, rres[pt].w};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        v[2 * i] += __uint_as_float(rw[i] << 16);
-        v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+        for (int i = 0; i < 4; i++) {
+          v[2 * i] += __uint_as_float(rw[i] << 16);
+          v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+        }
       }
+      uint4 o;
+      o.x = pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)); o.y = pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+      o.z = pack_bf16x2(fmaxf(v[4], 0.f), fmaxf(v[5], 0.f)); o.w = pack_bf16x2(fmaxf(v[6], 0.f), fmaxf(v[7], 0.f));
+      *(uint4*)(out + off) = o;
     }
-    uint4 o;
-    o.x = pack_bf16x2(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)); o.y = pack_bf16x2(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-    o.z = pack_bf16x2(fmaxf(v[4], 0.f), fmaxf(v[5], 0.f)); o.w = pack_bf16x2(fmaxf(v[6], 0.f), fmaxf(v[7], 0.f));
-    *(uint4*)(out + off) = o;
+    __syncthreads();     // every wave is done with the tile before the next one is written over it
   }
 }
 
@@ -441,7 +459,7 @@ int run_conv(ccx_resnet* r, const Conv& cv, int epi, const bf16_t* in, const Sta
              const bf16_t* resid, int n_chunks, hipStream_t st) {
   static const bool direct = getenv("CCX_RESNET_DIRECT") == nullptr || atoi(getenv("CCX_RESNET_DIRECT")) != 0;
   if (direct && cv.cin == 32 && cv.cout == 32 && cv.k == 3 && cv.stride == 1 && di.H % 4 == 0 && (epi == EPI_BF16_RELU || epi == EPI_BF16_ADD_RELU)) {
-    const dim3 grid(ccx_cdiv(di.W, 64), di.H / 4, n_chunks);
+    const dim3 grid(1, di.H / 4, n_chunks);
     {
       ccx_prof_scope ps(r->ctx, st, "conv3x3_c32_kernel", 2.0 * 9 * 32 * 32 * (double)n_chunks * di.H * di.W,
                         (double)n_chunks * di.H * di.W * 64.0 * (resid ? 3 : 2));
