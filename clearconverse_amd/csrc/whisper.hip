@@ -684,12 +684,16 @@ const std::vector<hipStream_t>& lane_streams_for(ccx_whisper* w, hipStream_t s0,
   return set;
 }
 
-int cross_split(int B, int H) {
+int cross_split(int B, int H, bool capped) {
   // enough blocks to fill the chip, and <= 256 keys per block (one 64-key chunk per wave)
   int ns = ccx_cdiv(512, B * H);
   if (ns < 6) ns = 6;
   if (ns > ccx_whisper::kCrossSplitMax) ns = ccx_whisper::kCrossSplitMax;
   if (B > 16) {
+    // lanes with the two-blocks-per-CU cap: 3 splits, i.e. two 64-key chunks per wave and half as many, longer-lived blocks,
+    // which suits the capped kernel better (pipeline step, ms: 2 splits 900, 3 891,
+    // 4 893, 6 912; per 64-sequence launch 49.9 us against 52.0 at 6 splits)
+    if (capped) ns = 3;
     // many sequences: CCX_CROSS_SPLIT=n overrides (1 = whole key range per block, no partials / combine).  Measured at
     // 64 sequences per lane: 6 splits 54.5 us per launch, 8 splits 56.8 us (a wave then owns 47 of a chunk's 64 keys).
     const char* e = getenv("CCX_CROSS_SPLIT");
@@ -710,7 +714,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
   const float scale_log2e = 0.125f * 1.4426950408889634f;
-  const int ns = cross_split(B, H);
+  const int ns = cross_split(B, H, w->cross_lds_pad > 0);
   const long pstride = (long)B * D;
   const long ro = b0;
   float* cur = w->dx + ro * D;     // stream (minus the pending partials); the step's embedding is in dx
