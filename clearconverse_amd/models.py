@@ -49,7 +49,8 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
 def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
-                seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None) -> Dict[str, object]:
+                seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None,
+                resnet_max_chunks: int = 96) -> Dict[str, object]:
     if not torch.cuda.is_available():
         raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
     dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
@@ -64,7 +65,7 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     embedder = XVectorEmbedder(W["xvector"], max_crops=int(emb_max_crops or max_crops), max_samples=16000 * 1200,
                                device=dev_index, ctx=ctx)
     # embedding model of the diarization pipeline (speaker-diarization-3.1 uses WeSpeaker ResNet-34, not pyannote/embedding)
-    diar_embedder = ResNetEmbedder(W["resnet34"], max_chunks=96, max_samples=160000, max_masks=512,
+    diar_embedder = ResNetEmbedder(W["resnet34"], max_chunks=int(resnet_max_chunks), max_samples=160000, max_masks=max(512, 3 * int(resnet_max_chunks)),
                                    device=dev_index, ctx=ctx)
     # one launch group of the segmentation nets holds seg_max_crops windows / seg_max_seconds of audio (≈60 B of device
     # buffers per sample): the batched pipeline raises both so that every window of a step shares one LSTM launch

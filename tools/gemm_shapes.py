@@ -10,7 +10,7 @@ from clearconverse_amd.models import load_models
 ctx = _lib.Context(0)
 B = 32
 audio = torch.from_numpy(np.stack([synthetic_clip(i, 30.0) for i in range(B)])).cuda().contiguous()
-models = load_models(None, 0, whisper_batch=192, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32)
+models = load_models(None, 0, whisper_batch=192, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32, emb_max_crops=44 * 32, resnet_max_chunks=21 * 32)
 bp = BatchPipeline(models, whisper_group=192, sample_len=8)
 bp.run_pinned(audio)
 torch.cuda.synchronize()

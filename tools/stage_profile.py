@@ -22,7 +22,7 @@ def report(pr, title, n=28):
 
 
 if mode == "stages":
-    models = load_models(None, 0, whisper_batch=8, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32)
+    models = load_models(None, 0, whisper_batch=8, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32, emb_max_crops=44 * 32, resnet_max_chunks=21 * 32)
     items = [{"waveform": torch.from_numpy(c).cuda(), "sample_rate": 16000} for c in clips]
     for name in ("vad_pipeline", "diarization"):
         kw = dict(min_speakers=1, max_speakers=2) if name == "diarization" else {}
@@ -34,7 +34,7 @@ if mode == "stages":
         pr.disable()
         report(pr, name, 18)
 else:
-    models = load_models(None, 0, whisper_batch=192, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32)
+    models = load_models(None, 0, whisper_batch=192, ctx=ctx, seed=0, seg_max_crops=52 * 32 + 16, seg_max_seconds=300.0 * 32, emb_max_crops=44 * 32, resnet_max_chunks=21 * 32)
     audio = torch.from_numpy(np.stack(clips)).cuda().contiguous()
     bp = BatchPipeline(models, whisper_group=192, sample_len=8)     # short decode: the host side of the other stages is the subject
     bp.run_pinned(audio)
