@@ -273,7 +273,7 @@ typedef const __attribute__((address_space(1))) void* ff_gptr_t;
 typedef __attribute__((address_space(3))) void* ff_lptr_t;
 
 __device__ __forceinline__ int ff_key1(int r) { return (r & 3) | (((r >> 4) & 3) << 2); }          // 256-byte rows
-__device__ __forceinline__ int ff_key2(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }   // 128-byte rows
+__device__ __forceinline__ int ff_key2(int r) { return ((r >> 1) & 1) | (((r >> 5) & 1) << 2); }   // 128-byte rows (chunk = 2 hq + s)
 
 __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                       const bf16_t* __restrict__ W1, const float* __restrict__ b1,
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, con
 
   const int rq = 16 * (l15 >> 2) + (l15 & 3);            // permuted operand row inside a 64-row block (+ 4 j)
   const int k1 = l15;                                    // ff_key1 of that row (u | q << 2), independent of j
-  const int k2 = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);   // ff_key2 of that row
+  const int k2 = ((l15 >> 1) & 1) | (((l15 >> 3) & 1) << 2);   // ff_key2 of that row
   // every wave issues the same 4 DMA instructions per stage, in stage order: with stages st+1, st+2 already issued,
   // vmcnt(8) means "my part of stage st has landed"; the barrier then makes all eight parts visible, and it also
   // tells that every wave is done reading stage st-1, whose buffer stage st+3 overwrites next.
