@@ -192,101 +192,133 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
     for (int i = 0; i < 16; i++) bias[i] = (nb + i < p.N) ? p.bias[nb + i] : 0.f;
   }
 
+  // Rows are finished in groups of GM row tiles: the residual rows of the whole group are requested before the first of
+  // them is needed (one memory round trip per group instead of one per row tile: the fp32-residual epilogue of a 256 x 256
+  // tile used to be eight dependent load -> add -> store rounds).
+  constexpr int GM = 4;
+  constexpr bool RES_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS || EPI == EPI_BF16_LRELU_AFFINE);
+  constexpr bool RES_BF16 = (EPI == EPI_BF16_ADD_RELU);
 #pragma unroll
-  for (int mt = 0; mt < MT; mt++) {
-    const int m = m0 + wr * MT * 16 + mt * 16 + l15;
-    if (m >= p.M) continue;
-    float v[16];
+  for (int mt0 = 0; mt0 < MT; mt0 += GM) {
+    long orow_[GM];
+    bool ok_[GM];
+    float4 rf[GM][4];
+    uint4 rb[GM][2];
+    if (EPI != EPI_HEADS) {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+      for (int g = 0; g < GM; g++) {
+        const int m = m0 + wr * MT * 16 + (mt0 + g) * 16 + l15;
+        bool valid = false;
+        long orow = 0;
+        if (m < p.M) orow = remap_row(p, m, valid);
+        ok_[g] = valid; orow_[g] = orow;
+        if (RES_F32) {
+          const bool has = valid && (EPI != EPI_BF16_LRELU_AFFINE || p.resid != nullptr);
+          if (has) {
+            const long rrow = (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
+            const float4* rp = (const float4*)(p.resid + rrow * p.ldr + nb);
 #pragma unroll
-      for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
-
-    if (EPI == EPI_HEADS) {
-      const int blk = nb / p.d_model + p.first_block;
-      const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
-      const int b = m / p.S, s = m - b * p.S;
-      bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
-      bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
-      uint4 o0, o1;
-      o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-      o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-      o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-      o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-      ((uint4*)dst)[0] = o0;
-      ((uint4*)dst)[1] = o1;
-      continue;
-    }
-
-    bool valid;
-    const long orow = remap_row(p, m, valid);
-    if (!valid) continue;
-
-    if (EPI == EPI_BF16_LRELU_AFFINE) {
-      if (p.resid) {
-        const float4* rp = (const float4*)(p.resid + orow * p.ldr + nb);
+            for (int i = 0; i < 4; i++) rf[g][i] = rp[i];
+          } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float4 r4 = rp[i];
-          v[4 * i + 0] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+            for (int i = 0; i < 4; i++) rf[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+        if (RES_BF16) {
+          if (valid && p.resid_bf16) {
+            const uint4* rp = (const uint4*)(p.resid_bf16 + orow * p.ldrb + nb);
+            rb[g][0] = rp[0]; rb[g][1] = rp[1];
+          } else {
+            rb[g][0] = make_uint4(0, 0, 0, 0); rb[g][1] = make_uint4(0, 0, 0, 0);
+          }
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
-        const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
-        const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
-        v[i] = t * sc + sh;
-      }
     }
-    if (EPI == EPI_BF16_ADD_RELU) {
-      if (p.resid_bf16) {
-        const uint4* rp = (const uint4*)(p.resid_bf16 + orow * p.ldrb + nb);
-        const uint4 r0 = rp[0], r1 = rp[1];
-        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+    for (int g = 0; g < GM; g++) {
+      const int mt = mt0 + g;
+      const int m = m0 + wr * MT * 16 + mt * 16 + l15;
+      if (m >= p.M) continue;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
+
+      if (EPI == EPI_HEADS) {
+        const int blk = nb / p.d_model + p.first_block;
+        const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
+        const int b = m / p.S, s = m - b * p.S;
+        bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
+        bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
+        uint4 o0, o1;
+        o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+        o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+        o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+        o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+        ((uint4*)dst)[0] = o0;
+        ((uint4*)dst)[1] = o1;
+        continue;
+      }
+
+      if (!ok_[g]) continue;
+      const long orow = orow_[g];
+
+      if (EPI == EPI_BF16_LRELU_AFFINE) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {     // zeros when there is no residual
+          v[4 * i + 0] += rf[g][i].x; v[4 * i + 1] += rf[g][i].y; v[4 * i + 2] += rf[g][i].z; v[4 * i + 3] += rf[g][i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
+          const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
+          const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
+          v[i] = t * sc + sh;
+        }
+      }
+      if (EPI == EPI_BF16_ADD_RELU) {
+        const uint32_t rw[8] = {rb[g][0].x, rb[g][0].y, rb[g][0].z, rb[g][0].w, rb[g][1].x, rb[g][1].y, rb[g][1].z, rb[g][1].w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {     // zeros when there is no residual
           v[2 * i] += __uint_as_float(rw[i] << 16);
           v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
         }
-      }
-#pragma unroll
-      for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
-    }
-    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
-      if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
-      }
-      if (EPI == EPI_BF16_RELU) {
 #pragma unroll
         for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
       }
-      bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
-      uint4 o0, o1;
-      o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-      o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-      o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-      o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-      ((uint4*)dst)[0] = o0;
-      ((uint4*)dst)[1] = o1;
-    } else {
-      if (EPI == EPI_F32_GELU_POS) {
+      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
+        if (EPI == EPI_BF16_GELU) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
-      }
-      if (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
-        const long rrow = p.resid_mod > 0 ? (orow % p.resid_mod) : orow;
-        const float4* rp = (const float4*)(p.resid + rrow * p.ldr + nb);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float4 r4 = rp[i];
-          v[4 * i + 0] += r4.x; v[4 * i + 1] += r4.y; v[4 * i + 2] += r4.z; v[4 * i + 3] += r4.w;
+          for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
         }
-      }
-      float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+        if (EPI == EPI_BF16_RELU) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+          for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
+        }
+        bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
+        uint4 o0, o1;
+        o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+        o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+        o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+        o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+        ((uint4*)dst)[0] = o0;
+        ((uint4*)dst)[1] = o1;
+      } else {
+        if (EPI == EPI_F32_GELU_POS) {
+#pragma unroll
+          for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
+        }
+        if (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            v[4 * i + 0] += rf[g][i].x; v[4 * i + 1] += rf[g][i].y; v[4 * i + 2] += rf[g][i].z; v[4 * i + 3] += rf[g][i].w;
+          }
+        }
+        float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+      }
     }
   }
 }
