@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const bf16_t* __restric
 //   * wave w owns hidden units 16w..16w+15 and all four of their gates (i|f|g|o): its 16 W_hh fragments
 //     (4 gates x K = 128) stay in registers for the whole sequence, and the cell update of a unit is
 //     lane-local (the accumulators of the four gates line up register by register);
-//   * H lives in LDS as bf16 (two buffers, 272-byte rows: conflict-free ds_read_b128 by 16 rows), one
+//   * H lives in LDS as bf16 (two buffers, 288-byte rows: conflict-free ds_read_b128 per tools/lds_bank_sim.py; 272 was two-way), one
 //     barrier per step;
 //   * the accumulators start from gx (x W_ih^T + b_ih + b_hh, fp32, from the GEMM), fetched three
 //     steps ahead of use.
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __restrict__ gx, const bf16_t* __restrict__ whh,
                                                              const int* __restrict__ row_off, const int* __restrict__ n_rows, int n_crops,
                                                              bf16_t* __restrict__ hout) {
-  __shared__ __attribute__((aligned(16))) bf16_t Hs[2][LSTM_SEQS][136];
+  __shared__ __attribute__((aligned(16))) bf16_t Hs[2][LSTM_SEQS][144];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, hq = lane >> 4;
   const int dir = blockIdx.y, c0 = blockIdx.x * LSTM_SEQS;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __rest
     gbase[r] = gx + r0 * 1024 + dir * 512 + unit;
     hbase[r] = hout + r0 * 256 + dir * 128 + unit;
   }
-  for (int i = tid; i < 2 * LSTM_SEQS * 136; i += 512) (&Hs[0][0][0])[i] = 0;
+  for (int i = tid; i < 2 * LSTM_SEQS * 144; i += 512) (&Hs[0][0][0])[i] = 0;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
 
   float gq[4][4][4];   // [ring slot][gate][row]: gx of steps s .. s+3
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(512) void lstm_recurrent_kernel(const float* __rest
       const int step = s0 + u;
       if (step >= nmax) break;            // uniform over the block
       fetch(step + 3, (u + 3) & 3);
-      const bf16_t(*Hc)[136] = Hs[step & 1];
-      bf16_t(*Hn)[136] = Hs[(step + 1) & 1];
+      const bf16_t(*Hc)[144] = Hs[step & 1];
+      bf16_t(*Hn)[144] = Hs[(step + 1) & 1];
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; g++) acc[g] = (f32x4){gq[u][g][0], gq[u][g][1], gq[u][g][2], gq[u][g][3]};
