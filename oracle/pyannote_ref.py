@@ -116,11 +116,6 @@ def xvector_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, weights: Opt
     return F.linear(pooled, sd["embedding.weight"].float(), sd["embedding.bias"].float())[0]
 
 
-def min_xvector_samples() -> int:
-    """Shortest crop for which every valid convolution still has at least 2 frames for the std."""
-    return 0
-
-
 def pyannet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, n_lstm: int = 4, hidden: int = 128) -> torch.Tensor:
     """PyanNet.forward: wav [B, 1, T] -> per-frame class scores [B, frames, C] (log-softmax for the
     powerset model, sigmoid for the multi-label one -- chosen by `sd['activation']`)."""
