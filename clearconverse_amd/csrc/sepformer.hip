@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void sep_final_norm_kernel(const float* __rest
 // 8.7 KB a token costs per layer); here a token's row is read once and written once.
 //   * block = 8 waves x 32 tokens; a wave normalises its tokens in registers (a row sits in the four lanes
 //     l15, l15+16, +32, +48) and keeps them as bf16 B-operand fragments for the whole tile;
-//   * W1 / W2 stream through LDS by LDS-DMA in stages of 128 hidden units (32 KB + 32 KB, two stages),
-//     XOR-swizzled on the DMA source (ff_key: conflict-free ds_read_b128 per tools/lds_bank_sim.py);
+//   * W1 / W2 stream through LDS by LDS-DMA in stages of 64 hidden units (16 KB + 16 KB) over a ring of four stages: two
+//     stages stay in flight across raw s_barriers (counted s_waitcnt vmcnt), XOR-swizzled on the DMA source (ff_key1 /
+//     ff_key2: conflict-free ds_read_b128 per tools/lds_bank_sim.py, tests/test_lds_layouts_cpu.py);
 //   * MFMA operands are swapped as in gemm_bf16.hip (weights as "A"), so a lane owns 16 consecutive hidden
 //     units of its token after GEMM 1 -- exactly a k-group of GEMM 2's B operand: relu + bf16 in registers,
 //     no LDS round trip for the hidden activation.  The k order inside a 64-block is permuted to match
