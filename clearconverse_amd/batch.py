@@ -58,7 +58,7 @@ class BatchPipeline:
         self._keep = (ptrs, lens)          # the tables must outlive the asynchronous launch
         return buf, n
 
-    def _whisper(self, crops: List[torch.Tensor], prompts: List[str]) -> List[dict]:
+    def _whisper(self, crops: List[torch.Tensor], prompts: List[str], prompt_ids: Optional[list] = None) -> List[dict]:
         """One 30 s window per crop (pinned schedule: every crop <= 30 s), batched in groups."""
         w = self.m["whisper_model"]
         tok = w.tokenizer
@@ -69,6 +69,8 @@ class BatchPipeline:
             w.log_mel(buf, n)
             w.encode(len(grp))
             pr = [w.initial_tokens(tok.encode(" " + p.strip()) if p else []) for p in prompts[i0:i0 + len(grp)]]
+            if prompt_ids is not None:
+                prompt_ids += pr
             out += w.decode_greedy(pr, sample_len=self.sample_len)
         return out
 
@@ -81,8 +83,10 @@ class BatchPipeline:
         return t0
 
     # ------------------------------------------------------------------ the pinned pipeline
-    def run_pinned(self, audio: torch.Tensor, timed: bool = False) -> Dict[str, object]:
-        """audio: [B, 480000] f32 on the GPU (raw clips).  Returns token records + counters."""
+    def run_pinned(self, audio: torch.Tensor, timed: bool = False, debug: bool = False) -> Dict[str, object]:
+        """audio: [B, 480000] f32 on the GPU (raw clips).  Returns token records + counters; with `debug` also every
+        intermediate the parity test compares with the oracle-composed pipeline (tests/pinned_oracle.py): the gated clips,
+        speaker profiles, segment / window similarities, separated sources, the picked source and the Whisper prompt ids."""
         m = self.m
         B, N = audio.shape
         assert N == 30 * SR and audio.is_cuda
@@ -172,10 +176,18 @@ class BatchPipeline:
         pick = (torch.nn.functional.cosine_similarity(se[1], pr, dim=1) > torch.nn.functional.cosine_similarity(se[0], pr, dim=1)).cpu().tolist()
         best = [srcs[1 if pick[i] else 0][i, :rn[i]] for i in range(len(regions))]
         t = self._mark("source_select", t, timed)
-        all_txt = self._whisper(reg_crops + best, [PROMPT_TWO_PEOPLE] * len(reg_crops) + [PROMPT_SINGLE] * len(best))
+        prompt_ids: Optional[list] = [] if debug else None
+        all_txt = self._whisper(reg_crops + best, [PROMPT_TWO_PEOPLE] * len(reg_crops) + [PROMPT_SINGLE] * len(best), prompt_ids)
         reg_txt, ov_txt = all_txt[:len(reg_crops)], all_txt[len(reg_crops):]
         t = self._mark("whisper", t, timed)
-        return dict(n_clips=B, audio_seconds=30.0 * B, whisper_calls=len(reg_crops) + len(best), tokens=sum(len(r["tokens"]) for r in reg_txt + ov_txt),
+        dbg = {}
+        if debug:
+            dbg = dict(den=den.cpu(), profile_embeds=pe_c.cpu(), profile_var=var_c.cpu(), profiles={k: v.cpu() for k, v in prof_all.items()},
+                       window_sims_full=win_sims.cpu(), window_owner=list(owner), separated=sep.cpu(), region_len=list(rn),
+                       source_sims=torch.stack([torch.nn.functional.cosine_similarity(se[k], pr, dim=1) for k in range(2)], dim=1).cpu(),
+                       pick=[int(x) for x in pick], prompt_ids=prompt_ids, whisper_inputs=[c.cpu() for c in reg_crops + best],
+                       regions=[(b, spk, s, e) for b, spk, s, e in regions], regular=[(b, spk, s, e) for b, spk, s, e in reg])
+        return dict(**dbg, n_clips=B, audio_seconds=30.0 * B, whisper_calls=len(reg_crops) + len(best), tokens=sum(len(r["tokens"]) for r in reg_txt + ov_txt),
                     embeds=len(crops) + len(reg_crops) + len(wins) + 2 * len(rcrops), separator_calls=len(rcrops),
                     vad_regions=n_vad, diar_turns=n_diar, records=reg_txt + ov_txt, sims=sims.cpu().tolist(), window_sims=int(win_sims.shape[0]))
 

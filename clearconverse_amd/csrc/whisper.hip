@@ -6,6 +6,7 @@
 // back/api.py:1286-1292, 1432-1438, 1474-1480).  Model semantics follow openai-whisper
 // model.py / decoding.py [UPSTREAM-RECALL -- not vendored in the reference]; the CPU restatement
 // the tests compare against is oracle/whisper_ref.py.
+#include <array>
 #include <map>
 #include <chrono>
 #include <math.h>
@@ -109,7 +110,7 @@ struct ccx_whisper {
   int max_prompt_cap = 0, sample_cap = 0;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
   // stream (stream capture is illegal there)
-  std::map<long, hipGraphExec_t> graphs;
+  std::map<std::array<int, 7>, hipGraphExec_t> graphs;
   hipStream_t own_stream = nullptr;
   hipEvent_t own_event = nullptr;
   // decode lanes: disjoint row ranges of one batch stepping concurrently on their own streams, staggered so
@@ -361,6 +362,9 @@ int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* r) {
   w->rules = *r;
   w->rules.suppress = nullptr;
   w->rules_set = true;
+  // captured step graphs bake the rule ids into the select kernel's parameters: drop them
+  for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
+  w->graphs.clear();
   return CCX_OK;
 }
 
@@ -870,9 +874,14 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
   // prompt buffer rows are `T` wide here
   TRY(upload_decode_state(w, tokens, lens.data(), T, B, 0.f, 0, stream));
   const long V = w->d.n_vocab;
+  w->cross_lds_pad = 0;   // single lane: the cross attention runs uncapped
   for (int t = 0; t < T; t++) {
-    // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it
-    TRY(dec_step(w, 0, B, logits_dev + (long)t * V, (long)T * V, t + 1 < T, 1, T, w->n_done, stream));
+    // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it.
+    // The logits GEMM stores whole 16-column groups, so it writes the padded workspace rows (ld = Vpad) and the n_vocab valid
+    // columns are copied out: writing [B, T, V] in place would spill V % 16 columns into the next row / past the tensor.
+    TRY(dec_step(w, 0, B, w->dlogits, w->Vpad, t + 1 < T, 1, T, w->n_done, stream));
+    CCX_HIP(ctx, hipMemcpy2DAsync(logits_dev + (long)t * V, (size_t)T * V * 4, w->dlogits, (size_t)w->Vpad * 4, (size_t)V * 4, B,
+                                  hipMemcpyDeviceToDevice, stream));
   }
   return CCX_OK;
 }
@@ -969,7 +978,9 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   if (use_graph && total_steps > 1) {
     for (int i = 0; i < nl; i++) {
       // graphs are specific to (lane rows, sample_len, max_prompt)
-      const long key = ((((long)lanes[i].b0 * 4099 + lanes[i].B) * 4099 + sample_len) * 4099 + max_prompt) * 2 + (w->sampling ? 1 : 0);
+      // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
+      const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0);
+      const std::array<int, 7> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

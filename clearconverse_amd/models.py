@@ -57,9 +57,8 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     ctx = ctx or _lib.Context(dev_index)
     W = state_dicts if state_dicts is not None else build_state_dicts(config, whisper_dims, sep_dims, seed)
     wd, wsd = WhisperDims(**W["whisper_dims"]), W["whisper"]
-    sd_ = SepDims(**W["sep_dims"])
+    sd_ = SepDims(**W["sep_dims"])      # the geometry the separator weights were built with (broadcast manifest included)
     whisper = WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds)
-    sd_ = sep_dims or SepDims()
     separator = SepformerSeparator(sd_, W["sepformer"], max_tokens=sep_tokens, max_utts=64,
                                    device=dev_index, ctx=ctx)
     embedder = XVectorEmbedder(W["xvector"], max_crops=int(emb_max_crops or max_crops), max_samples=16000 * 1200,

@@ -1,0 +1,104 @@
+"""CPU pipeline composed from oracle/* that restates what `BatchPipeline.run_pinned` (the path bench.py times) must
+compute for ONE clip under the pinned 30 s schedule.  TEST INFRASTRUCTURE ONLY.
+
+Every stage follows the reference statement it stands for (/root/reference/back/api.py):
+  load_audio            832-834   gate on the whole clip (noise_reduction_amount) + x / (max|x| + 1e-8)
+  speaker profiles      893-959   crop -> enhance_audio (gate + peak normalise, 345-352) -> embedding; quality = torch.var of
+                                  the un-enhanced crop; profile = variance-weighted SUM of the turn embeddings
+  regular segments      1462-1470 embedding of the crop, cosine similarity with the speaker's profile
+  sliding windows       961-1006  0.8 s windows every 0.4 s over the overlap-bearing segment, similarity with every profile
+  separation + pick     1066-1105 separate_batch(region) -> each source / (max|source| + 1e-8) -> embedding -> the source whose
+                                  similarity with the region speaker's profile is larger (strict >, first wins a tie)
+  transcription         1286-1292 Whisper on the picked source, fixed prompts
+The numerical models are the oracle restatements (parity unpinned); the composition is what this adds."""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from clearconverse_amd.audio import SCHEDULE_30S
+from oracle import pyannote_ref as P
+from oracle import sepformer_ref as S
+from oracle import spectral_gate_ref as G
+from oracle import whisper_ref as R
+
+SR = 16000
+
+
+def peak(x: np.ndarray, eps: float) -> np.ndarray:
+    m = float(np.max(np.abs(x))) if x.size else 0.0
+    if eps > 0:
+        return x / (m + eps)
+    return x / m if m > 0 else x           # enhance_audio divides only when the peak is > 0 (back/api.py:350-351)
+
+
+def run_clip(clip: np.ndarray, sds: Dict[str, object], sep_dims, nra: float = 0.5, win: float = 0.8, hop: float = 0.4) -> dict:
+    """clip: raw 30 s waveform.  sds: the state dicts the GPU models were built from (models.build_state_dicts)."""
+    den = peak(G.reduce_noise(clip, SR, prop_decrease=nra), 1e-8).astype(np.float32)
+    sched = [(spk, int(s * SR), int(e * SR)) for spk, s, e in SCHEDULE_30S]
+    xsd = sds["xvector"]
+
+    def embed(x: np.ndarray) -> torch.Tensor:
+        return P.xvector_forward(xsd, torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))[None])
+
+    # profiles
+    pe, var = [], []
+    for _, s, e in sched:
+        crop = den[s:e]
+        clean = peak(G.reduce_noise(crop, SR, prop_decrease=nra), 0.0)
+        pe.append(embed(clean))
+        var.append(float(torch.var(torch.from_numpy(crop))))
+    profiles = {}
+    for spk in ("A", "B"):
+        cols = [j for j, (s_, _, _) in enumerate(sched) if s_ == spk]
+        tot = sum(var[j] for j in cols)
+        profiles[spk] = sum(pe[j] * (var[j] / tot) for j in cols)
+    # regular segments
+    cos = torch.nn.functional.cosine_similarity
+    sims = [float(cos(embed(den[s:e]), profiles[spk], dim=0)) for spk, s, e in sched[2:]]
+    # sliding windows over the two overlap-bearing segments
+    wsims = []
+    for spk, s, e in sched[:2]:
+        pos = s
+        while pos + int(win * SR) <= e:
+            em = embed(den[pos:pos + int(win * SR)])
+            wsims.append([float(cos(em, profiles["A"], dim=0)), float(cos(em, profiles["B"], dim=0))])
+            pos += int(hop * SR)
+    # scripted regions, separation, source pick
+    regions = []
+    for spk, s, e in sched[:2]:
+        cut = int(7.0 * SR) if spk == "A" else int(9.0 * SR)
+        regions += [("A" if spk == "A" else "B", s, cut), ("B" if spk == "A" else "A", cut, e)]
+    orc_sep = S.SepformerRef(S.SepDims(**sep_dims.__dict__), sds["sepformer"])
+    separated, source_sims, sources = [], [], []
+    for spk, s, e in regions:
+        sep = orc_sep.separate(torch.from_numpy(den[s:e])[None])[0].numpy()           # [T, 2]
+        srcs = [peak(sep[:, k], 1e-8).astype(np.float32) for k in range(2)]
+        separated.append(sep)
+        sources.append(srcs)
+        source_sims.append([float(cos(embed(srcs[k]), profiles[spk], dim=0)) for k in range(2)])
+    return dict(den=den, profile_embeds=torch.stack(pe), profile_var=var, profiles=profiles, sims=sims, window_sims=wsims,
+                regions=regions, separated=separated, sources=sources, source_sims=source_sims,
+                regular=[den[s:e] for _, s, e in sched[2:]])
+
+
+def whisper_check(orc: R.WhisperRef, orules: R.Rules, wave: np.ndarray, prompt: List[int], gpu_tokens: List[int], sample_len: int,
+                  eot: int, tol: float):
+    """Teacher-force the GPU's tokens through the oracle on the ORACLE's own input waveform: every token must be an
+    eps-argmax of the oracle's filtered logits, and equal to the argmax where the oracle's margin exceeds 2 eps.
+    Returns (#steps, #steps with a decisive margin)."""
+    mel = R.pad_or_trim(R.log_mel_spectrogram(torch.from_numpy(wave))[:, : len(wave) // 160], 3000)
+    xa = orc.encode(mel[None])
+    forced = list(gpu_tokens) + ([eot] if len(gpu_tokens) < sample_len else [])
+    seq, sampled, decisive = list(prompt), [], 0
+    for i, t in enumerate(forced):
+        lg = R.apply_filters(orc.decoder_logits(torch.tensor([seq]), xa)[0, -1], sampled, orules)
+        top2 = torch.topk(lg, 2).values
+        assert float(lg[t]) >= float(top2[0]) - tol, (i, t, int(lg.argmax()), float(top2[0] - lg[t]))
+        if float(top2[0] - top2[1]) > 2 * tol:
+            assert t == int(lg.argmax()), (i, t, int(lg.argmax()))
+            decisive += 1
+        seq.append(t); sampled.append(t)
+    return len(forced), decisive

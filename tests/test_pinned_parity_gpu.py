@@ -1,0 +1,168 @@
+"""-m gpu: parity of the path bench.py TIMES -- `BatchPipeline.run_pinned` (clearconverse_amd/batch.py) -- not only of its kernels.
+
+(a) two clips, mini Whisper / 2-layer SepFormer, full-size speaker nets: every intermediate run_pinned produces is compared with
+    the CPU pipeline composed from oracle/* in tests/pinned_oracle.py (which cites the reference statements it follows).
+(b) `ccx_peak_normalize` through the C ABI against x / (max|x| + eps) (/root/reference/back/api.py:834 and 350-351).
+(c) BASELINE configs[3] at FULL size (32 x 30 s clips, small.en, full-depth SepFormer, whisper group 192, hipGraph decode lanes):
+    the oracle cannot run that in seconds, so it is checked through a size-independent property -- a clip's records do not depend
+    on its batch mates: clips run alone give bit-identical tokens / similarities.
+
+Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages): gated clip rel-L2 2e-3 (spectral gate alone: 2e-3); profile
+embeddings rel-L2 3e-2 (gate error feeds the embedder); cosine similarities abs 2e-2; separated waveforms rel-L2 5e-2; the
+picked source must agree wherever the oracle's two similarities differ by more than 4e-2; Whisper tokens are eps-argmax
+(eps 0.15: gate + separator + encoder + decoder errors in series) of the oracle's filtered logits under teacher forcing and equal
+where its margin exceeds 2 eps."""
+import numpy as np
+import pytest
+import torch
+
+from clearconverse_amd.audio import synthetic_clip
+from clearconverse_amd.weights import SepDims, WhisperDims
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().flatten(); b = torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
+    from clearconverse_amd.batch import BatchPipeline
+    from clearconverse_amd.models import build_state_dicts, load_models
+    from clearconverse_amd.tokenizer import DecodeRules
+    from oracle import whisper_ref as R
+    from tests import pinned_oracle as O
+
+    wd, sdims = WhisperDims.mini(2, 128), SepDims(n_layers=2)
+    sds = build_state_dicts(None, whisper_dims=wd, sep_dims=sdims, seed=7)
+    models = load_models(None, 0, whisper_batch=16, ctx=ccx_ctx, state_dicts=sds, sep_tokens=60_000, max_crops=128)
+    sample_len = 6
+    bp = BatchPipeline(models, whisper_group=16, sample_len=sample_len)
+    clips = [synthetic_clip(40 + i, 30.0) for i in range(2)]
+    r = bp.run_pinned(torch.from_numpy(np.stack(clips)).cuda(), debug=True)
+
+    rules = DecodeRules()
+    orules = R.Rules(suppress=tuple(rules.suppress))
+    orc_w = R.WhisperRef(R.Dims(**wd.__dict__), sds["whisper"])
+    tok = models["whisper_model"].tokenizer
+    n_reg, n_decisive, n_steps = 2 * 2, 0, 0
+    worst = {}
+
+    def track(name, v):
+        worst[name] = max(worst.get(name, 0.0), float(v))
+
+    for b, clip in enumerate(clips):
+        o = O.run_clip(clip, sds, sdims)
+        track("den", _rel(r["den"][b], o["den"]))
+        assert _rel(r["den"][b], o["den"]) < 2e-3
+        for j in range(4):
+            track("profile_embed", _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]))
+            assert _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]) < 3e-2
+            assert abs(float(r["profile_var"][b, j]) - o["profile_var"][j]) < 1e-3 * o["profile_var"][j]
+        for spk in ("A", "B"):
+            track("profile", _rel(r["profiles"][spk][b], o["profiles"][spk]))
+            assert _rel(r["profiles"][spk][b], o["profiles"][spk]) < 3e-2
+        for j in range(2):
+            d = abs(r["sims"][2 * b + j] - o["sims"][j]); track("sim", d)
+            assert d < 2e-2, (b, j, r["sims"][2 * b + j], o["sims"][j])
+        rows = [i for i, ow in enumerate(r["window_owner"]) if ow // 2 == b]
+        assert len(rows) == len(o["window_sims"]) == 42
+        ws = r["window_sims_full"][rows]
+        d = float((ws - torch.tensor(o["window_sims"])).abs().max()); track("window_sim", d)
+        assert d < 2e-2
+        for k in range(4):
+            i = 4 * b + k
+            assert r["regions"][i][1:] == o["regions"][k] and r["region_len"][i] == o["regions"][k][2] - o["regions"][k][1]
+            n = r["region_len"][i]
+            e = _rel(r["separated"][i, :n], o["separated"][k]); track("separated", e)
+            assert e < 5e-2, (i, e)
+            ss = o["source_sims"][k]
+            d = float((r["source_sims"][i] - torch.tensor(ss)).abs().max()); track("source_sim", d)
+            assert d < 2e-2
+            if abs(ss[1] - ss[0]) > 4e-2:
+                assert r["pick"][i] == int(ss[1] > ss[0]), (i, ss, r["pick"][i])
+        # Whisper: prompts are ids, inputs are the oracle's OWN waveforms (regular crop / the source at the GPU's pick)
+        for k in range(2):
+            i = 2 * b + k
+            want = models["whisper_model"].initial_tokens(tok.encode(" " + "This is a conversation between two people."))
+            assert r["prompt_ids"][i] == want
+            a, c = O.whisper_check(orc_w, orules, o["regular"][k], want, r["records"][i]["tokens"], sample_len, rules.eot, 0.15)
+            n_steps += a; n_decisive += c
+        for k in range(4):
+            i = n_reg + 4 * b + k
+            want = models["whisper_model"].initial_tokens(tok.encode(" " + "This is a single speaker talking."))
+            assert r["prompt_ids"][i] == want
+            src = o["sources"][k][r["pick"][4 * b + k]]
+            a, c = O.whisper_check(orc_w, orules, src, want, r["records"][i]["tokens"], sample_len, rules.eot, 0.15)
+            n_steps += a; n_decisive += c
+    print("worst errors vs the oracle-composed pipeline:", {k: f"{v:.2e}" for k, v in worst.items()},
+          f"whisper steps {n_steps}, decisive-margin steps {n_decisive}")
+    assert n_steps == 12 * sample_len
+    for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
+        models[m].close()
+
+
+@pytest.mark.parametrize("eps", [0.0, 1e-8])
+def test_peak_normalize_matches_reference_formula(ccx_ctx, eps):
+    """K3 (`peak_normalize_kernel`): y[b, :n_b] = x / (max|x| + eps); eps == 0 divides only when the peak is > 0
+    (enhance_audio, back/api.py:350-351); columns past n_b are not written.  Ragged lengths, an all-zero row, a one-sample row."""
+    g = torch.Generator().manual_seed(3)
+    lens = [480000, 1, 12345, 64, 1025, 300000, 7]
+    stride = 480000
+    x = torch.zeros(len(lens), stride)
+    for i, n in enumerate(lens):
+        x[i, :n] = torch.randn(n, generator=g) * (0.1 + i)
+    x[3] = 0.0                                   # silent row
+    x[1, 0] = -0.25                              # one sample, negative peak
+    xd = x.cuda()
+    y = torch.full_like(xd, 7.0)
+    nd = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_peak_normalize(ccx_ctx.handle, xd.data_ptr(), y.data_ptr(), stride, nd.data_ptr(), len(lens), float(eps),
+                                                 int(torch.cuda.current_stream().cuda_stream)), "ccx_peak_normalize")
+    torch.cuda.synchronize()
+    y = y.cpu()
+    for i, n in enumerate(lens):
+        row = x[i, :n]
+        m = float(row.abs().max())
+        # the kernel multiplies by the reciprocal: one rounding more than the division
+        ref = row / (m + eps) if eps > 0 else (row / m if m > 0 else row)
+        assert float((y[i, :n] - ref).abs().max()) <= 2.0 ** -22 * max(1.0, float(ref.abs().max())), i
+        assert bool((y[i, n:] == 7.0).all()), i
+        if m > 0:
+            assert abs(float(y[i, :n].abs().max()) - m / (m + eps)) < 1e-6
+    assert bool((y[3, :64] == 0.0).all())        # silent row stays silent for both flavours (0 / 1e-8 = 0)
+
+
+def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
+    """BASELINE configs[3] exactly as bench.py builds it (32 x 30 s clips, full small.en, full-depth SepFormer, whisper group 192 ->
+    3 decode lanes on their own hipGraphs), short sample_len.  Clips 0, 13 and 31 are then run ALONE through the same objects
+    (6 sequences: small-batch decode path, one lane): tokens, log-probs and similarities must be identical."""
+    from clearconverse_amd.batch import BatchPipeline
+    from clearconverse_amd.models import build_state_dicts, load_models
+    B, sample_len = 32, 5
+    sds = build_state_dicts(None, seed=0)
+    assert sds["whisper_dims"]["n_audio_layer"] == 12 and sds["sep_dims"]["n_layers"] == 8      # full size
+    models = load_models(None, 0, whisper_batch=192, ctx=ccx_ctx, seed=0, state_dicts=sds, seg_max_crops=52 * B + 16,
+                         seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B)
+    del sds
+    bp = BatchPipeline(models, whisper_group=192, sample_len=sample_len)
+    audio = torch.from_numpy(np.stack([synthetic_clip(i, 30.0) for i in range(B)])).cuda().contiguous()
+    full = bp.run_pinned(audio, debug=True)
+    assert full["whisper_calls"] == 6 * B and full["separator_calls"] == 4 * B and len(full["records"]) == 6 * B
+    assert all(len(x["tokens"]) == sample_len or len(x["tokens"]) < sample_len for x in full["records"])
+    for b in (0, 13, 31):
+        one = bp.run_pinned(audio[b:b + 1].contiguous(), debug=True)
+        assert one["sims"] == full["sims"][2 * b:2 * b + 2], b
+        rows = [i for i, ow in enumerate(full["window_owner"]) if ow // 2 == b]
+        assert torch.equal(one["window_sims_full"], full["window_sims_full"][rows]), b
+        assert one["pick"] == full["pick"][4 * b:4 * b + 4], b
+        for k in range(4):
+            n = one["region_len"][k]
+            assert torch.equal(one["separated"][k, :n], full["separated"][4 * b + k, :n]), (b, k)
+        idx = [2 * b, 2 * b + 1] + [2 * B + 4 * b + k for k in range(4)]
+        for j, i in enumerate(idx):
+            assert one["records"][j]["tokens"] == full["records"][i]["tokens"], (b, j)
+            assert abs(one["records"][j]["sum_logprob"] - full["records"][i]["sum_logprob"]) < 1e-3, (b, j)
+    for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
+        models[m].close()

@@ -107,6 +107,36 @@ def test_decoder_logits_mini(mini):
     got = m.decoder_logits(toks.numpy()).cpu()
     ref = _oracle(dims, sd).decoder_logits(toks, xa.cpu())   # oracle decoder on the GPU's own xa: isolates the decoder
     assert _rel(got, ref) < 3e-2, _rel(got, ref)
+    # n_vocab % 16 == 8: the logits GEMM stores whole 16-column groups, so an in-place [B, T, V] store would overwrite the first
+    # 8 logits of the next row (b + 1, t = 0) at t = T - 1 -- every (b, t) row is checked on its own
+    for b in range(2):
+        for t in range(9):
+            assert _rel(got[b, t], ref[b, t]) < 3e-2, (b, t)
+    assert float((got[1, 0, :8] - ref[1, 0, :8]).abs().max()) < 0.05 * float(ref[1, 0].abs().max())
+    # T == 1 (a single teacher-forced position)
+    one = m.decoder_logits(toks[:, :1].numpy()).cpu()
+    assert one.shape == (2, 1, dims.n_vocab) and _rel(one[:, 0], ref[:, 0]) < 3e-2
+
+
+def test_set_rules_invalidates_captured_graphs(mini):
+    """ccx_whisper_set_rules after a decode: the captured step graphs hold the old rule ids in their kernel parameters and must
+    be dropped.  With eot moved to another id the finished flag follows the NEW id."""
+    dims, sd, m = mini
+    rules, _ = _rules()
+    clips, n, dev = _clips([4.0])
+    m.log_mel(dev, n); m.encode(1)
+    a = m.decode_greedy([[rules.sot]], sample_len=6)[0]["tokens"]
+    r2 = DecodeRules()
+    r2.max_initial_timestamp_index = 3           # first token must now be a timestamp <= 0.06 s
+    m.set_rules(r2)
+    try:
+        b = m.decode_greedy([[r2.sot_prev, 900, r2.sot]], sample_len=6)[0]["tokens"]     # prompt > 1: the first sampling step is a replayed step
+        assert r2.timestamp_begin <= b[0] <= r2.timestamp_begin + 3, b
+        c = m.decode_greedy([[r2.sot]], sample_len=6)[0]["tokens"]
+        assert r2.timestamp_begin <= c[0] <= r2.timestamp_begin + 3, c
+    finally:
+        m.set_rules(rules)
+    assert m.decode_greedy([[rules.sot]], sample_len=6)[0]["tokens"] == a
 
 
 def _check_greedy(dims, sd, m, xa, prompts, sample_len, tol):
