@@ -7,11 +7,12 @@
     the oracle cannot run that in seconds, so it is checked through a size-independent property -- a clip's records do not depend
     on its batch mates: clips run alone give bit-identical tokens / similarities.
 
-Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages): gated clip rel-L2 2e-3 (spectral gate alone: 2e-3); profile
-embeddings rel-L2 3e-2 (gate error feeds the embedder); cosine similarities abs 2e-2; separated waveforms rel-L2 5e-2; the
-picked source must agree wherever the oracle's two similarities differ by more than 4e-2; Whisper tokens are eps-argmax
-(eps 0.15: gate + separator + encoder + decoder errors in series) of the oracle's filtered logits under teacher forcing and equal
-where its margin exceeds 2 eps."""
+Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages; about 4x the worst deviation measured on MI355X, which is given
+in brackets): gated + normalised clip rel-L2 1e-5 [2e-7]; profile embeddings rel-L2 1e-2 [2.5e-3]; cosine similarities abs 2e-4
+[3e-5] (seeded random x-vector weights give similarities of 0.996-0.999, so the tolerance is set against their spread, not
+against 1); separated waveforms rel-L2 2e-2 [4e-3]; the picked source must agree wherever the oracle's two similarities differ
+by more than 5e-4; Whisper tokens are eps-argmax (eps 0.1: gate + separator + encoder + decoder errors in series) of the oracle's
+filtered logits under teacher forcing and equal where its margin exceeds 2 eps (27 of the 72 steps)."""
 import numpy as np
 import pytest
 import torch
@@ -46,7 +47,7 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
     orules = R.Rules(suppress=tuple(rules.suppress))
     orc_w = R.WhisperRef(R.Dims(**wd.__dict__), sds["whisper"])
     tok = models["whisper_model"].tokenizer
-    n_reg, n_decisive, n_steps = 2 * 2, 0, 0
+    n_reg, n_decisive, n_steps, n_pick = 2 * 2, 0, 0, 0
     worst = {}
 
     def track(name, v):
@@ -55,49 +56,50 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
     for b, clip in enumerate(clips):
         o = O.run_clip(clip, sds, sdims)
         track("den", _rel(r["den"][b], o["den"]))
-        assert _rel(r["den"][b], o["den"]) < 2e-3
+        assert _rel(r["den"][b], o["den"]) < 1e-5
         for j in range(4):
             track("profile_embed", _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]))
-            assert _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]) < 3e-2
+            assert _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]) < 1e-2
             assert abs(float(r["profile_var"][b, j]) - o["profile_var"][j]) < 1e-3 * o["profile_var"][j]
         for spk in ("A", "B"):
             track("profile", _rel(r["profiles"][spk][b], o["profiles"][spk]))
-            assert _rel(r["profiles"][spk][b], o["profiles"][spk]) < 3e-2
+            assert _rel(r["profiles"][spk][b], o["profiles"][spk]) < 1e-2
         for j in range(2):
             d = abs(r["sims"][2 * b + j] - o["sims"][j]); track("sim", d)
-            assert d < 2e-2, (b, j, r["sims"][2 * b + j], o["sims"][j])
+            assert d < 2e-4, (b, j, r["sims"][2 * b + j], o["sims"][j])
         rows = [i for i, ow in enumerate(r["window_owner"]) if ow // 2 == b]
         assert len(rows) == len(o["window_sims"]) == 42
         ws = r["window_sims_full"][rows]
         d = float((ws - torch.tensor(o["window_sims"])).abs().max()); track("window_sim", d)
-        assert d < 2e-2
+        assert d < 2e-4
         for k in range(4):
             i = 4 * b + k
             assert r["regions"][i][1:] == o["regions"][k] and r["region_len"][i] == o["regions"][k][2] - o["regions"][k][1]
             n = r["region_len"][i]
             e = _rel(r["separated"][i, :n], o["separated"][k]); track("separated", e)
-            assert e < 5e-2, (i, e)
+            assert e < 2e-2, (i, e)
             ss = o["source_sims"][k]
             d = float((r["source_sims"][i] - torch.tensor(ss)).abs().max()); track("source_sim", d)
-            assert d < 2e-2
-            if abs(ss[1] - ss[0]) > 4e-2:
+            assert d < 2e-4
+            if abs(ss[1] - ss[0]) > 5e-4:
+                n_pick += 1
                 assert r["pick"][i] == int(ss[1] > ss[0]), (i, ss, r["pick"][i])
         # Whisper: prompts are ids, inputs are the oracle's OWN waveforms (regular crop / the source at the GPU's pick)
         for k in range(2):
             i = 2 * b + k
             want = models["whisper_model"].initial_tokens(tok.encode(" " + "This is a conversation between two people."))
             assert r["prompt_ids"][i] == want
-            a, c = O.whisper_check(orc_w, orules, o["regular"][k], want, r["records"][i]["tokens"], sample_len, rules.eot, 0.15)
+            a, c = O.whisper_check(orc_w, orules, o["regular"][k], want, r["records"][i]["tokens"], sample_len, rules.eot, 0.1)
             n_steps += a; n_decisive += c
         for k in range(4):
             i = n_reg + 4 * b + k
             want = models["whisper_model"].initial_tokens(tok.encode(" " + "This is a single speaker talking."))
             assert r["prompt_ids"][i] == want
             src = o["sources"][k][r["pick"][4 * b + k]]
-            a, c = O.whisper_check(orc_w, orules, src, want, r["records"][i]["tokens"], sample_len, rules.eot, 0.15)
+            a, c = O.whisper_check(orc_w, orules, src, want, r["records"][i]["tokens"], sample_len, rules.eot, 0.1)
             n_steps += a; n_decisive += c
     print("worst errors vs the oracle-composed pipeline:", {k: f"{v:.2e}" for k, v in worst.items()},
-          f"whisper steps {n_steps}, decisive-margin steps {n_decisive}")
+          f"whisper steps {n_steps}, decisive-margin steps {n_decisive}, decisive source picks {n_pick} of 8")
     assert n_steps == 12 * sample_len
     for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
         models[m].close()
@@ -163,6 +165,8 @@ def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
         idx = [2 * b, 2 * b + 1] + [2 * B + 4 * b + k for k in range(4)]
         for j, i in enumerate(idx):
             assert one["records"][j]["tokens"] == full["records"][i]["tokens"], (b, j)
-            assert abs(one["records"][j]["sum_logprob"] - full["records"][i]["sum_logprob"]) < 1e-3, (b, j)
+            # identical tokens; the log-probabilities differ in the last fp32 digits because the cross attention of a 64-row lane
+            # is cut into 3 key ranges and that of a 6-row batch into 6 (different merge order of the online softmax)
+            assert abs(one["records"][j]["sum_logprob"] - full["records"][i]["sum_logprob"]) < 5e-3, (b, j)
     for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
         models[m].close()
