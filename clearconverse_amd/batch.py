@@ -86,7 +86,16 @@ class BatchPipeline:
     def run_pinned(self, audio: torch.Tensor, timed: bool = False, debug: bool = False) -> Dict[str, object]:
         """audio: [B, 480000] f32 on the GPU (raw clips).  Returns token records + counters; with `debug` also every
         intermediate the parity test compares with the oracle-composed pipeline (tests/pinned_oracle.py): the gated clips,
-        speaker profiles, segment / window similarities, separated sources, the picked source and the Whisper prompt ids."""
+        speaker profiles, segment / window similarities, separated sources, the picked source and the Whisper prompt ids.
+        Sequential schedule: front end, then Whisper, on the caller's stream."""
+        st = self._front(audio, timed, debug)
+        prompt_ids: Optional[list] = [] if debug else None
+        all_txt = self._whisper(st["whisper_crops"], st["whisper_prompts"], prompt_ids)
+        return self._finish(st, all_txt, prompt_ids, timed)
+
+    def _front(self, audio: torch.Tensor, timed: bool = False, debug: bool = False) -> dict:
+        """Everything of the pinned pipeline before Whisper (gate, VAD, diarization, profiles, similarities, sliding windows,
+        separation, source pick) on the current stream.  MFMA- / latency-bound; the Whisper decode that follows is HBM-bound."""
         m = self.m
         B, N = audio.shape
         assert N == 30 * SR and audio.is_cuda
@@ -176,11 +185,28 @@ class BatchPipeline:
         pick = (torch.nn.functional.cosine_similarity(se[1], pr, dim=1) > torch.nn.functional.cosine_similarity(se[0], pr, dim=1)).cpu().tolist()
         best = [srcs[1 if pick[i] else 0][i, :rn[i]] for i in range(len(regions))]
         t = self._mark("source_select", t, timed)
-        prompt_ids: Optional[list] = [] if debug else None
-        all_txt = self._whisper(reg_crops + best, [PROMPT_TWO_PEOPLE] * len(reg_crops) + [PROMPT_SINGLE] * len(best), prompt_ids)
-        reg_txt, ov_txt = all_txt[:len(reg_crops)], all_txt[len(reg_crops):]
-        t = self._mark("whisper", t, timed)
+        st = dict(B=B, n_reg=len(reg_crops), whisper_crops=reg_crops + best,
+                  whisper_prompts=[PROMPT_TWO_PEOPLE] * len(reg_crops) + [PROMPT_SINGLE] * len(best), n_vad=n_vad, n_diar=n_diar,
+                  embeds=len(crops) + len(reg_crops) + len(wins) + 2 * len(rcrops), separator_calls=len(rcrops), sims=sims,
+                  win_sims=win_sims, t=t)
+        if debug:
+            st["dbg"] = dict(den=den, pe_c=pe_c, var_c=var_c, prof_all=prof_all, owner=owner, sep=sep, rn=rn, se=se, pr=pr, pick=pick,
+                             regions=regions, reg=reg)
+        return st
+
+    def _finish(self, st: dict, all_txt: List[dict], prompt_ids: Optional[list], timed: bool) -> Dict[str, object]:
+        """Assemble run_pinned's result from the front-end state and the decoded records."""
+        B, n_reg = st["B"], st["n_reg"]
+        reg_crops, best = st["whisper_crops"][:n_reg], st["whisper_crops"][n_reg:]
+        sims, win_sims = st["sims"], st["win_sims"]
+        reg_txt, ov_txt = all_txt[:n_reg], all_txt[n_reg:]
+        self._mark("whisper", st["t"], timed)
         dbg = {}
+        debug = "dbg" in st
+        if debug:
+            d = st["dbg"]
+            den, pe_c, var_c, prof_all, owner, sep, rn, se, pr, pick, regions, reg = (d[k] for k in (
+                "den", "pe_c", "var_c", "prof_all", "owner", "sep", "rn", "se", "pr", "pick", "regions", "reg"))
         if debug:
             dbg = dict(den=den.cpu(), profile_embeds=pe_c.cpu(), profile_var=var_c.cpu(), profiles={k: v.cpu() for k, v in prof_all.items()},
                        window_sims_full=win_sims.cpu(), window_owner=list(owner), separated=sep.cpu(), region_len=list(rn),
@@ -188,8 +214,72 @@ class BatchPipeline:
                        pick=[int(x) for x in pick], prompt_ids=prompt_ids, whisper_inputs=[c.cpu() for c in reg_crops + best],
                        regions=[(b, spk, s, e) for b, spk, s, e in regions], regular=[(b, spk, s, e) for b, spk, s, e in reg])
         return dict(**dbg, n_clips=B, audio_seconds=30.0 * B, whisper_calls=len(reg_crops) + len(best), tokens=sum(len(r["tokens"]) for r in reg_txt + ov_txt),
-                    embeds=len(crops) + len(reg_crops) + len(wins) + 2 * len(rcrops), separator_calls=len(rcrops),
-                    vad_regions=n_vad, diar_turns=n_diar, records=reg_txt + ov_txt, sims=sims.cpu().tolist(), window_sims=int(win_sims.shape[0]))
+                    embeds=st["embeds"], separator_calls=st["separator_calls"],
+                    vad_regions=st["n_vad"], diar_turns=st["n_diar"], records=reg_txt + ov_txt, sims=sims.cpu().tolist(), window_sims=int(win_sims.shape[0]))
+
+
+    # ------------------------------------------------------------------ software-pipelined schedule
+    def run_pinned_pipelined(self, audios: Sequence[torch.Tensor], debug: bool = False) -> List[Dict[str, object]]:
+        """The same work as [run_pinned(a) for a in audios], software-pipelined across batches: while the Whisper windows of
+        batch i decode (HBM-bound cross attention + latency-bound chain, on the decode lanes' own high-priority streams, driven
+        by a worker thread -- the C call releases the GIL), the front end and the encoder of batch i + 1 (MFMA-bound) run on a
+        second stream.  Two Whisper instances (models["whisper_models"]) alternate, so an encode never overwrites cross-KV that
+        is still being decoded.  Results are identical to the sequential schedule: same kernels, same order per batch."""
+        from concurrent.futures import ThreadPoolExecutor
+        whs = self.m.get("whisper_models") or [self.m["whisper_model"]]
+        if len(whs) < 2:
+            raise _lib.CcxError("run_pinned_pipelined needs two Whisper instances: load_models(..., whisper_instances=2)")
+        dev = audios[0].device
+        if not hasattr(self, "_front_stream"):
+            self._front_stream = torch.cuda.Stream(device=dev)
+            self._dec_streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in whs]     # lane 0 of each instance
+            torch.cuda.synchronize(dev)
+            for w, s_ in zip(whs, self._dec_streams):       # the lane probe needs an idle device: do it before anything overlaps
+                w.prepare_lanes(s_)
+        torch.cuda.current_stream(dev).synchronize()      # the inputs were produced on the caller's stream
+        grp = min(self.group, whs[0].max_batch)
+
+        def decode_task(k: int, prompts, ready: torch.cuda.Event):
+            with torch.cuda.stream(self._dec_streams[k]):
+                self._dec_streams[k].wait_event(ready)
+                return whs[k].decode_greedy(prompts, sample_len=self.sample_len)
+
+        out: List[Dict[str, object]] = []
+        pending = []                       # (front state, [futures], prompt ids)
+        slot_busy = [None] * len(whs)
+        unit = 0
+        with ThreadPoolExecutor(max_workers=1) as ex, torch.cuda.stream(self._front_stream):
+            for audio in audios:
+                st = self._front(audio, False, debug)
+                crops, prompts = st["whisper_crops"], st["whisper_prompts"]
+                futs, pids = [], []
+                for i0 in range(0, len(crops), grp):
+                    k = unit % len(whs)
+                    if slot_busy[k] is not None:
+                        slot_busy[k].result()                      # the instance's previous windows are decoded
+                    w = whs[k]
+                    part = crops[i0:i0 + grp]
+                    buf, n = self._pad_batch(part)
+                    w.log_mel(buf, n)
+                    w.encode(len(part))
+                    ready = torch.cuda.Event()
+                    ready.record(self._front_stream)
+                    tok = w.tokenizer
+                    pr = [w.initial_tokens(tok.encode(" " + p.strip()) if p else []) for p in prompts[i0:i0 + len(part)]]
+                    pids += pr
+                    fut = ex.submit(decode_task, k, pr, ready)
+                    slot_busy[k] = fut
+                    futs.append((fut, buf))                        # buf stays referenced until its kernels have run
+                    unit += 1
+                pending.append((st, futs, pids))
+                # hand finished batches over as soon as their decodes are done (keeps at most two batches of state alive)
+                while len(pending) > 2:
+                    st0, f0, p0 = pending.pop(0)
+                    out.append(self._finish(st0, [r for f, _ in f0 for r in f.result()], p0 if debug else None, False))
+            for st0, f0, p0 in pending:
+                out.append(self._finish(st0, [r for f, _ in f0 for r in f.result()], p0 if debug else None, False))
+            self._front_stream.synchronize()
+        return out
 
 
 def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:

@@ -40,6 +40,7 @@ struct DecAttnParams {
   float* part_o;        // partials [B][H][nsplit][64]
   float* part_ml;       // [B][H][nsplit][2]
   int lds_pad;          // dynamic LDS the blocks claim without using it: caps the blocks per CU (see ccx_whisper_decode)
+  int stream_mode;      // cross attention only: 1 = dec_cross_stream_kernel (few waves, few bytes in flight per CU)
 };
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out, hipStream_t stream);
 

@@ -635,6 +635,159 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
   }
 }
 
+// Cross attention for decode lanes that overlap other lanes' latency-bound chains ("lean streaming").  The chain kernels of
+// the other lanes are slowed mostly by the memory queue of the CU they share with streaming waves (MI355X_MICROARCH.md,
+// handoff-1to1: 0.8 us idle, 2.3-2.8 us beside 8 streaming waves, 1.2-1.5 beside 2-5), so this variant keeps FEW waves per CU
+// and FEW bytes per wave in flight while still covering HBM latency: a wave owns one contiguous key range and rolls through it
+// in 32-key pieces (4 K + 4 V wave loads = 8 KB), the next piece always requested before the current one is reduced
+// (two named register sets; hipcc leaves the younger 8 loads in flight: s_waitcnt vmcnt(8)).
+// NP = 32-key pieces per wave (compile-time: the loop is fully unrolled into straight-line code, because with a real loop
+// hipcc keeps the loop-carried piece in other registers than it loads into and copies it at the loop end behind a vmcnt(0)).
+template <bool FINAL, int NP>
+__global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) {
+  __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, split = blockIdx.y;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int g = lane >> 3, c = lane & 7;
+  const int T = p.T;
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int kbeg = split * per;
+  const int kend = (kbeg + per < T) ? kbeg + per : T;
+  // contiguous range of this wave, in multiples of 32 keys
+  const int per_w = (((kend - kbeg) + 3) / 4 + 31) & ~31;
+  // wave-uniform by construction; readfirstlane makes it provable, so the loop below branches on scalars (s_cbranch_scc)
+  // instead of masking lanes, and hipcc can count its loads (vmcnt(8)) instead of draining them
+  const int w0 = __builtin_amdgcn_readfirstlane(kbeg + wave * per_w);
+  const int w1 = __builtin_amdgcn_readfirstlane((w0 + per_w < kend) ? w0 + per_w : kend);
+
+  const bf16_t* Kb = p.k + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Vb = p.v + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+
+  float sm = -1e30f, sl = 0.f, so[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) so[j] = 0.f;
+  float q[8];
+  {
+    const float4* qp = (const float4*)(p.q + ((long)b * p.H + h) * 64 + 8 * c);
+    const float4 a = qp[0], d = qp[1];
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = d.x; q[5] = d.y; q[6] = d.z; q[7] = d.w;
+  }
+  auto load = [&](bf16x8 (&kf)[4], bf16x8 (&vf)[4], int base) {
+    long off[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      int key = base + it * 8 + g;
+      key = key < w1 ? key : kend - 1;    // clamped rows (one cache line) are masked below
+      off[it] = (long)key * 64;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) kf[it] = __builtin_nontemporal_load((const bf16x8*)(Kb + off[it]));   // K first: the scores need it first
+#pragma unroll
+    for (int it = 0; it < 4; it++) vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vb + off[it]));
+  };
+  auto reduce = [&](const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int base) {
+    float s[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) a = fmaf(q[j], bf16_to_f32((bf16_t)kf[it][j]), a);
+      a = group8_sum(a) * p.scale_log2e;
+      s[it] = (base + it * 8 + g < w1) ? a : -INFINITY;
+    }
+    float mn = sm;
+#pragma unroll
+    for (int it = 0; it < 4; it++) mn = fmaxf(mn, s[it]);
+    const float al = __builtin_amdgcn_exp2f(sm - mn);
+    sl *= al;
+#pragma unroll
+    for (int j = 0; j < 8; j++) so[j] *= al;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const float pe = __builtin_amdgcn_exp2f(s[it] - mn);
+      sl += pe;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[j] = fmaf(pe, bf16_to_f32((bf16_t)vf[it][j]), so[j]);
+    }
+    sm = mn;
+  };
+  // q is consumed once here so that hipcc waits for it BEFORE the loop (a wait for q inside the loop would drain the
+  // K/V requests that are younger than it)
+  {
+    float qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) qs += q[j];
+    asm volatile("" ::"v"(qs));
+  }
+  {
+    // no branch around a request or a reduce: one code path, exact load counts.  Pieces past the end of the wave's range
+    // re-read its last key row (one cache line) and are masked to -inf scores.  sched_barrier pins the order
+    // request(i+1) -> reduce(i): at most two pieces (16 KB) and at least one (8 KB) in flight per wave.
+    bf16x8 kA[4], vA[4], kB[4], vB[4];
+    load(kA, vA, w0);
+#pragma unroll
+    for (int i = 0; i < NP; i += 2) {
+      const int base = w0 + 32 * i;
+      if (i + 1 < NP) load(kB, vB, base + 32);
+      __builtin_amdgcn_sched_barrier(0);
+      reduce(kA, vA, base);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < NP) load(kA, vA, base + 64);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < NP) reduce(kB, vB, base + 32);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  {
+    auto merge_with = [&](float om, float ol, const float (&oo)[8]) {
+      const float mx = fmaxf(sm, om);
+      const float wa = __builtin_amdgcn_exp2f(sm - mx), wb = __builtin_amdgcn_exp2f(om - mx);
+      sl = sl * wa + ol * wb;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[j] = so[j] * wa + oo[j] * wb;
+      sm = mx;
+    };
+    float om, ol, oo[8];
+    om = dpp_mov<0x128>(sm); ol = dpp_mov<0x128>(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = dpp_mov<0x128>(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor16(sm); ol = lane_xor16(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor16(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor32(sm); ol = lane_xor32(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor32(so[j]);
+    merge_with(om, ol, oo);
+  }
+  if (g == 0) {
+    sm_m[wave][c] = sm; sm_l[wave][c] = sl;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sm_o[wave][c][j] = so[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int cc = tid >> 3, j = tid & 7;
+    float mx = fmaxf(fmaxf(sm_m[0][cc], sm_m[1][cc]), fmaxf(sm_m[2][cc], sm_m[3][cc]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float ww = __builtin_amdgcn_exp2f(sm_m[w][cc] - mx);
+      l += ww * sm_l[w][cc];
+      o += ww * sm_o[w][cc][j];
+    }
+    if (FINAL) {
+      p.out_bf16[((long)b * p.H + h) * 64 + tid] = f32_to_bf16(o / l);
+    } else {
+      const long pbase = ((long)b * p.H + h) * gridDim.y + split;
+      p.part_o[pbase * 64 + tid] = o;
+      if (tid == 0) { p.part_ml[pbase * 2] = mx; p.part_ml[pbase * 2 + 1] = l; }
+    }
+  }
+}
+
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out,
                              hipStream_t stream) {
   CCX_REQUIRE(ctx, B > 0 && p.H > 0 && nsplit >= 1, "dec_attention: bad shape");
@@ -642,9 +795,29 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
   dim3 grid(B * p.H, nsplit);
   {
     const double keys = p.pos ? 0.0 : (double)p.T;  // self-attention length varies per row: not priced
-    ccx_prof_scope ps(ctx, stream, final_out ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
+    // the cross attention keeps its profile label whatever variant runs (self attention: <true> with pos)
+    ccx_prof_scope ps(ctx, stream, p.pos ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
                       (double)B * p.H * keys * 64 * 2 * 2);
-    if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
+    // pieces per wave: keys per block / 4 waves, rounded up to 32 (the kernel's own formula)
+    const int np_need = p.pos ? 0 : ((ccx_cdiv(ccx_cdiv(p.T, nsplit), 4) + 31) / 32);
+    if (p.stream_mode && !p.pos && np_need <= 12) {
+      const int pad = p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0;
+#define CCX_CROSS_STREAM_LAUNCH(F, NP)                                                                                       \
+  do {                                                                                                                       \
+    static bool attr_ = false;                                                                                               \
+    if (!attr_) {                                                                                                            \
+      CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_cross_stream_kernel<F, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+      attr_ = true;                                                                                                          \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((dec_cross_stream_kernel<F, NP>), grid, dim3(256), pad, stream, p);                                   \
+  } while (0)
+      if (final_out) {
+        if (np_need <= 4) CCX_CROSS_STREAM_LAUNCH(true, 4); else if (np_need <= 6) CCX_CROSS_STREAM_LAUNCH(true, 6); else CCX_CROSS_STREAM_LAUNCH(true, 12);
+      } else {
+        if (np_need <= 4) CCX_CROSS_STREAM_LAUNCH(false, 4); else if (np_need <= 6) CCX_CROSS_STREAM_LAUNCH(false, 6); else CCX_CROSS_STREAM_LAUNCH(false, 12);
+      }
+#undef CCX_CROSS_STREAM_LAUNCH
+    } else if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
     else {
       static bool attr_set = false;
       if (p.lds_pad > 0 && !attr_set) {   // static + dynamic LDS beyond 64 KB needs the opt-in

@@ -110,7 +110,7 @@ struct ccx_whisper {
   int max_prompt_cap = 0, sample_cap = 0;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
   // stream (stream capture is illegal there)
-  std::map<std::array<int, 7>, hipGraphExec_t> graphs;
+  std::map<std::array<int, 8>, hipGraphExec_t> graphs;
   hipStream_t own_stream = nullptr;
   hipEvent_t own_event = nullptr;
   // decode lanes: disjoint row ranges of one batch stepping concurrently on their own streams, staggered so
@@ -118,6 +118,7 @@ struct ccx_whisper {
   // modest (3-4 % at 192 sequences): the small kernels slow down 3-5x while HBM is saturated by another lane.
   static constexpr int kMaxLanes = 4;
   int cross_lds_pad = 0;                     // see ccx_whisper_decode: occupancy cap of the cross-attention blocks while lanes overlap
+  int cross_stream = 0;                      // 1: lean-streaming cross attention (dec_cross_stream_kernel) for batches > 16
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
                                              // queue run strictly one after the other, so lanes are picked by a probe
@@ -515,14 +516,19 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   w->sample_cap = d.n_text_ctx;
   TRY(dev_alloc(w, &w->prompt, (size_t)B * w->max_prompt_cap, true));
   TRY(dev_alloc(w, &w->gen, (size_t)B * w->sample_cap, true));
-  CCX_HIP(w->ctx, hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
+  // decode streams get the highest priority: when other work shares the GPU (the front end of the next batch on another
+  // stream) the short, latency-bound chain kernels should get the next free wave slot.  CCX_LANE_PRIORITY=0 disables.
+  int prio_least = 0, prio_greatest = 0;
+  CCX_HIP(w->ctx, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  { const char* e = getenv("CCX_LANE_PRIORITY"); if (e && atoi(e) == 0) prio_greatest = 0; }
+  CCX_HIP(w->ctx, hipStreamCreateWithPriority(&w->own_stream, hipStreamNonBlocking, prio_greatest));
   CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->own_event, hipEventDisableTiming));
   for (int i = 0; i < ccx_whisper::kMaxLanes; i++) {
     CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_start[i], hipEventDisableTiming));
     CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_poll[0][i], hipEventDisableTiming));
     CCX_HIP(w->ctx, hipEventCreateWithFlags(&w->lane_poll[1][i], hipEventDisableTiming));
   }
-  for (int i = 0; i < ccx_whisper::kLanePool; i++) CCX_HIP(w->ctx, hipStreamCreateWithFlags(&w->lane_pool[i], hipStreamNonBlocking));
+  for (int i = 0; i < ccx_whisper::kLanePool; i++) CCX_HIP(w->ctx, hipStreamCreateWithPriority(&w->lane_pool[i], hipStreamNonBlocking, prio_greatest));
   TRY(dev_alloc(w, &w->probe_sink, (size_t)64, true));
   CCX_HIP(w->ctx, hipHostMalloc((void**)&w->poll_host, 2 * ccx_whisper::kMaxLanes * sizeof(int), 0));
   w->finalized = true;
@@ -688,7 +694,14 @@ const std::vector<hipStream_t>& lane_streams_for(ccx_whisper* w, hipStream_t s0,
   return set;
 }
 
-int cross_split(int B, int H, bool capped) {
+int cross_split(int B, int H, bool capped, bool lean = false) {
+  if (lean && B > 16) {
+    // lean streaming: one block owns the whole key range of a (sequence, head) -- 12 rolling 32-key pieces per wave, FINAL output,
+    // no partials and no combine launch; CCX_CROSS_SPLIT overrides
+    const char* e = getenv("CCX_CROSS_SPLIT");
+    const int forced = e ? atoi(e) : 0;
+    return (forced >= 1 && forced <= ccx_whisper::kCrossSplitMax) ? forced : 1;
+  }
   // enough blocks to fill the chip, and <= 256 keys per block (one 64-key chunk per wave)
   int ns = ccx_cdiv(512, B * H);
   if (ns < 6) ns = 6;
@@ -718,7 +731,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
   const float scale_log2e = 0.125f * 1.4426950408889634f;
-  const int ns = cross_split(B, H, w->cross_lds_pad > 0);
+  const int ns = cross_split(B, H, w->cross_lds_pad > 0, w->cross_stream != 0);
   const long pstride = (long)B * D;
   const long ro = b0;
   float* cur = w->dx + ro * D;     // stream (minus the pending partials); the step's embedding is in dx
@@ -787,6 +800,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
     ap.lds_pad = w->cross_lds_pad;
+    ap.stream_mode = (w->cross_stream && B > 16) ? 1 : 0;
     if (B > 16) {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
       if (ns > 1) TRY(ccx_launch_dec_combine(ctx, part_o, part_ml, ns, dattn, B, H, stream));
@@ -875,6 +889,7 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
   TRY(upload_decode_state(w, tokens, lens.data(), T, B, 0.f, 0, stream));
   const long V = w->d.n_vocab;
   w->cross_lds_pad = 0;   // single lane: the cross attention runs uncapped
+  w->cross_stream = 0;
   for (int t = 0; t < T; t++) {
     // the select kernel (prompt phase) advances cur_tok/pos; on the last step it would read prompt[T] -> skip it.
     // The logits GEMM stores whole 16-column groups, so it writes the padded workspace rows (ld = Vpad) and the n_vocab valid
@@ -883,6 +898,15 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
     CCX_HIP(ctx, hipMemcpy2DAsync(logits_dev + (long)t * V, (size_t)T * V * 4, w->dlogits, (size_t)w->Vpad * 4, (size_t)V * 4, B,
                                   hipMemcpyDeviceToDevice, stream));
   }
+  return CCX_OK;
+}
+
+int ccx_whisper_prepare_lanes(ccx_whisper* w, void* stream_) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, w->finalized, "whisper: not finalized");
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : w->own_stream;
+  CCX_HIP(w->ctx, hipDeviceSynchronize());
+  (void)lane_streams_for(w, stream, ccx_whisper::kMaxLanes - 1);
   return CCX_OK;
 }
 
@@ -945,7 +969,10 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   // drops 924 -> 897 ms (3 blocks per CU: 910; 4: 919; 1: 979).  CCX_CROSS_LDS_PAD overrides.
   {
     static const int forced_pad = [] { const char* e = getenv("CCX_CROSS_LDS_PAD"); return e ? atoi(e) : -1; }();
-    w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? 65536 : 0);
+    static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 0; }();
+    w->cross_stream = lean;
+    // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight
+    w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (lean ? 98304 : (nl > 1 ? 65536 : 0));
   }
   struct Lane { int b0, B; hipStream_t s; hipGraphExec_t exec; };
   Lane lanes[ccx_whisper::kMaxLanes];
@@ -979,8 +1006,8 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     for (int i = 0; i < nl; i++) {
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
-      const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0);
-      const std::array<int, 7> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad};
+      const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
+      const std::array<int, 8> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

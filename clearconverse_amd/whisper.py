@@ -125,6 +125,12 @@ class WhisperModel:
                                                            out.data_ptr(), _lib.current_stream_ptr()), "ccx_whisper_decoder_logits")
         return out
 
+    def prepare_lanes(self, stream: Optional[torch.cuda.Stream] = None):
+        """Pick the decode lanes' internal streams for decodes issued on `stream` (default: the current stream) now, on an
+        idle device -- needed before decodes are overlapped with work on other streams (batch.run_pinned_pipelined)."""
+        sp = int((stream or torch.cuda.current_stream()).cuda_stream)
+        self.ctx.check(self.lib.ccx_whisper_prepare_lanes(self.handle, sp), "ccx_whisper_prepare_lanes")
+
     def decode_greedy(self, prompts: Sequence[Sequence[int]], sample_len: Optional[int] = None) -> List[dict]:
         """Greedy DecodingTask.run over the currently encoded windows (temperature 0)."""
         return self.decode(prompts, sample_len, temperature=0.0)

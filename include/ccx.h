@@ -135,6 +135,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
                        int sample_len, float temperature, uint64_t seed, int32_t* tokens_out, int32_t* n_tokens_out,
                        float* sum_logprob_out, float* no_speech_prob_out, void* stream);
 
+/* Batch-driver helper with no counterpart in the reference (it decodes one window at a time, back/api.py:1286): picks, once, the
+ * internal streams on which the lanes of a large decode batch will run beside `stream` (HIP maps streams onto a few hardware
+ * queues; the choice is made by a short timing probe, which must not be disturbed by other work on the GPU).  Call it on an
+ * otherwise idle device before decodes are overlapped with other streams; ccx_whisper_decode does it lazily otherwise. */
+int ccx_whisper_prepare_lanes(ccx_whisper* w, void* stream);
+
 /* ---- RE-SepFormer separator (replaces self.separator, reference back/api.py:713-717; call at
  *      back/api.py:1077 `separated = self.separator.separate_batch(subsegment)`) -------------------- */
 

@@ -71,3 +71,29 @@ def test_pinned_batch_driver_counts(models):
     assert len(r["records"]) == r["whisper_calls"] and all(len(x["tokens"]) <= 8 for x in r["records"])
     assert all(np.isfinite(s) for s in r["sims"])
     assert set(bp.stage_ms) >= {"load_audio_gate", "vad", "diarization", "profiles", "separate", "whisper"}
+
+
+def test_pipelined_schedule_equals_sequential(ccx_ctx):
+    """batch.run_pinned_pipelined (front end of batch i + 1 on a second stream while batch i decodes on a worker thread, two
+    Whisper instances alternating, several Whisper groups per batch) must return exactly what run_pinned returns batch by batch."""
+    from clearconverse_amd.batch import BatchPipeline
+    from clearconverse_amd.models import load_models
+    m = load_models(None, 0, whisper_batch=8, ctx=ccx_ctx, whisper_dims=WhisperDims.mini(2, 128), sep_dims=SepDims(n_layers=2),
+                    sep_tokens=60_000, max_crops=128, whisper_instances=2)
+    bp = BatchPipeline(m, whisper_group=8, sample_len=6)            # 12 windows per 2-clip batch -> two groups per batch
+    batches = [torch.from_numpy(np.stack([synthetic_clip(10 * k + i, 30.0) for i in range(2)])).cuda() for k in range(3)]
+    seq = [bp.run_pinned(a, debug=True) for a in batches]
+    for _ in range(2):                                              # twice: the second pass replays captured graphs
+        pip = bp.run_pinned_pipelined(batches, debug=True)
+        assert len(pip) == len(seq)
+        for a, b in zip(seq, pip):
+            assert [r["tokens"] for r in a["records"]] == [r["tokens"] for r in b["records"]]
+            assert [r["sum_logprob"] for r in a["records"]] == [r["sum_logprob"] for r in b["records"]]
+            assert a["sims"] == b["sims"] and a["pick"] == b["pick"] and a["prompt_ids"] == b["prompt_ids"]
+            assert torch.equal(a["window_sims_full"], b["window_sims_full"]) and torch.equal(a["separated"], b["separated"])
+            for k in ("whisper_calls", "separator_calls", "embeds", "vad_regions", "diar_turns"):
+                assert a[k] == b[k]
+    for k in ("separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
+        m[k].close()
+    for w in m["whisper_models"]:
+        w.close()
