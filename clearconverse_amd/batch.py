@@ -239,10 +239,17 @@ class BatchPipeline:
         torch.cuda.current_stream(dev).synchronize()      # the inputs were produced on the caller's stream
         grp = min(self.group, whs[0].max_batch)
 
-        def decode_task(k: int, prompts, ready: torch.cuda.Event):
+        trace = getattr(self, "trace", None)       # optional list: (what, batch unit, t_start, t_end) host times of both threads
+
+        def decode_task(k: int, prompts, ready: torch.cuda.Event, u: int):
             with torch.cuda.stream(self._dec_streams[k]):
                 self._dec_streams[k].wait_event(ready)
-                return whs[k].decode_greedy(prompts, sample_len=self.sample_len)
+                if trace is not None:
+                    ready.synchronize(); t0 = time.perf_counter()
+                r = whs[k].decode_greedy(prompts, sample_len=self.sample_len)
+                if trace is not None:
+                    trace.append(("decode", u, t0, time.perf_counter()))
+                return r
 
         out: List[Dict[str, object]] = []
         pending = []                       # (front state, [futures], prompt ids)
@@ -250,7 +257,10 @@ class BatchPipeline:
         unit = 0
         with ThreadPoolExecutor(max_workers=1) as ex, torch.cuda.stream(self._front_stream):
             for audio in audios:
+                tf0 = time.perf_counter()
                 st = self._front(audio, False, debug)
+                if trace is not None:
+                    self._front_stream.synchronize(); trace.append(("front", unit, tf0, time.perf_counter()))
                 crops, prompts = st["whisper_crops"], st["whisper_prompts"]
                 futs, pids = [], []
                 for i0 in range(0, len(crops), grp):
@@ -258,16 +268,19 @@ class BatchPipeline:
                     if slot_busy[k] is not None:
                         slot_busy[k].result()                      # the instance's previous windows are decoded
                     w = whs[k]
+                    te0 = time.perf_counter()
                     part = crops[i0:i0 + grp]
                     buf, n = self._pad_batch(part)
                     w.log_mel(buf, n)
                     w.encode(len(part))
                     ready = torch.cuda.Event()
                     ready.record(self._front_stream)
+                    if trace is not None:
+                        ready.synchronize(); trace.append(("encode", unit, te0, time.perf_counter()))
                     tok = w.tokenizer
                     pr = [w.initial_tokens(tok.encode(" " + p.strip()) if p else []) for p in prompts[i0:i0 + len(part)]]
                     pids += pr
-                    fut = ex.submit(decode_task, k, pr, ready)
+                    fut = ex.submit(decode_task, k, pr, ready, unit)
                     slot_busy[k] = fut
                     futs.append((fut, buf))                        # buf stays referenced until its kernels have run
                     unit += 1

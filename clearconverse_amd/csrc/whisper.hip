@@ -746,13 +746,21 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   int* pos = w->pos + b0;
   const long cross_off = ro * H * w->Spad * 64, self_off = ro * H * Tc * 64;
   int pend_n = 0;
+  // CCX_DEC_W_CACHED=1: the layers' weight matrices by default-policy loads (Infinity Cache residency across steps)
+  static const int w_cached = [] { const char* e = getenv("CCX_DEC_W_CACHED"); return e ? atoi(e) : 0; }();
   auto ln_linear = [&](int epi, const bf16_t* W, const float* bias, int N, const float* g, const float* bta, void* out, long ldo,
                        DecLinearParams* extra) -> int {
     DecLinearParams lp;
     if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias; lp.out = out; lp.ldo = ldo;
+    lp.w_cached = w_cached;
     int rc;
-    if (B > 16) {
+    // CCX_DEC_FUSE_LN=1: LayerNorm stays in the linear's prologue for every batch size (16-row panels, decoder.hip);
+    // 0 (default): more than 16 rows are normalised once by a stand-alone kernel.  Measured at 3 x 64 rows: fused 880.7 ms per
+    // pipeline step, stand-alone 871.9 -- the fused kernel needs the whole register file of its CU and lives longer, which costs
+    // more beside another lane's cross attention than the three launches it saves.
+    static const int fuse_ln = [] { const char* e = getenv("CCX_DEC_FUSE_LN"); return e ? atoi(e) : 0; }();
+    if (B > 16 && !(fuse_ln && D <= 768)) {
       // many sequences: normalise ONCE in a stand-alone kernel instead of redundantly in every weight-panel block
       rc = ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, g, bta, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
       if (rc) return rc;
@@ -771,6 +779,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = D; lp.K = K; lp.W = W; lp.ldw = K; lp.bias = bias; lp.act = a; lp.lda = K;
+    lp.w_cached = w_cached;
     lp.part_o = part_o; lp.part_ml = part_ml; lp.nsplit = ns;
     lp.out = pend; lp.ldo = D; lp.pend_stride = pstride;
     int rc = ccx_launch_dec_linear(ctx, act, DEPI_PARTIAL, lp, stream);
@@ -969,7 +978,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   // drops 924 -> 897 ms (3 blocks per CU: 910; 4: 919; 1: 979).  CCX_CROSS_LDS_PAD overrides.
   {
     static const int forced_pad = [] { const char* e = getenv("CCX_CROSS_LDS_PAD"); return e ? atoi(e) : -1; }();
-    static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 0; }();
+    static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 1; }();
     w->cross_stream = lean;
     // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight
     w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (lean ? 98304 : (nl > 1 ? 65536 : 0));
