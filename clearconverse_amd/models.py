@@ -16,9 +16,9 @@ from .denoise import SpectralGate
 from .pipelines import SpeakerDiarization, VoiceActivityDetection
 from .separator import SepformerSeparator
 from .speaker import ResNetEmbedder, SegmentationNet, XVectorEmbedder
-from .weights import (SepDims, WhisperDims, find_sepformer_checkpoint, find_whisper_checkpoint, synthetic_pyannet_state_dict,
-                      synthetic_resnet34_state_dict, synthetic_sepformer_state_dict, synthetic_whisper_state_dict,
-                      synthetic_xvector_state_dict)
+from .weights import (SepDims, WhisperDims, find_pipeline_config, find_pyannote_checkpoint, find_sepformer_checkpoint,
+                      find_whisper_checkpoint, synthetic_pyannet_state_dict, synthetic_resnet34_state_dict,
+                      synthetic_sepformer_state_dict, synthetic_whisper_state_dict, synthetic_xvector_state_dict)
 from .whisper import WhisperModel
 
 
@@ -35,14 +35,24 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
         wd = whisper_dims or WhisperDims.small_en()
         wsd = synthetic_whisper_state_dict(wd, seed=seed)
     sd_ = sep_dims or SepDims()
+    sep_ck = find_sepformer_checkpoint() if sep_dims is None else None
+    # pyannote-side networks (reference back/api.py:776-792): real checkpoints when the hub cache holds them, seeded otherwise
+    synth = {"xvector": lambda: synthetic_xvector_state_dict(seed=seed + 2), "pyannet_diar": lambda: synthetic_pyannet_state_dict(7, seed=seed + 3),
+             "pyannet_vad": lambda: synthetic_pyannet_state_dict(3, seed=seed + 4), "resnet34": lambda: synthetic_resnet34_state_dict(seed=seed + 5)}
+    nets, sources = {}, {"whisper": "checkpoint" if ck is not None else f"synthetic-seed{seed}",
+                         "sepformer": "checkpoint" if sep_ck is not None else f"synthetic-seed{seed + 1}"}
+    for kind, make in synth.items():
+        real = find_pyannote_checkpoint(kind)
+        nets[kind] = real if real is not None else make()
+        sources[kind] = "checkpoint" if real is not None else "synthetic"
     return {
-        "whisper_dims": dict(wd.__dict__), "whisper": wsd, "whisper_source": "checkpoint" if ck is not None else f"synthetic-seed{seed}",
+        "whisper_dims": dict(wd.__dict__), "whisper": wsd, "whisper_source": sources["whisper"],
         "sep_dims": dict(sd_.__dict__),
-        "sepformer": (find_sepformer_checkpoint() if sep_dims is None else None) or synthetic_sepformer_state_dict(sd_, seed=seed + 1),
-        "xvector": synthetic_xvector_state_dict(seed=seed + 2),
-        "pyannet_diar": synthetic_pyannet_state_dict(7, seed=seed + 3),
-        "pyannet_vad": synthetic_pyannet_state_dict(3, seed=seed + 4),
-        "resnet34": synthetic_resnet34_state_dict(seed=seed + 5),
+        "sepformer": sep_ck or synthetic_sepformer_state_dict(sd_, seed=seed + 1),
+        **nets,
+        "weights_sources": sources,
+        # pipeline hyper-parameters: the pipelines' own config.yaml when on disk, the published values otherwise
+        "vad_params": find_pipeline_config("vad"), "diarization_params": find_pipeline_config("diarization"),
     }
 
 
@@ -57,6 +67,7 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     ctx = ctx or _lib.Context(dev_index)
     W = state_dicts if state_dicts is not None else build_state_dicts(config, whisper_dims, sep_dims, seed)
     wd, wsd = WhisperDims(**W["whisper_dims"]), W["whisper"]
+    vp, dp = W.get("vad_params") or {}, W.get("diarization_params") or {}
     sd_ = SepDims(**W["sep_dims"])      # the geometry the separator weights were built with (broadcast manifest included)
     # whisper_instances = 2: the software-pipelined batch driver (batch.py) encodes batch i + 1 into one instance while batch i
     # is still decoding out of the other (each holds its own cross-KV, workspaces and step graphs; the weights are 0.5 GB)
@@ -85,8 +96,10 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
         "whisper_models": whispers,
         "separator": separator,
         "embedding_model": embedder,
-        "vad_pipeline": VoiceActivityDetection(seg_vad, batch=seg_crops),
-        "diarization": SpeakerDiarization(seg_diar, diar_embedder, batch=seg_crops),
+        "vad_pipeline": VoiceActivityDetection(seg_vad, batch=seg_crops, **{k: vp[k] for k in ("onset", "offset", "min_duration_on", "min_duration_off") if k in vp}),
+        "diarization": SpeakerDiarization(seg_diar, diar_embedder, batch=seg_crops,
+                                          **{k: dp[k] for k in ("threshold", "min_cluster_size", "min_duration_off") if k in dp}),
+        "weights_sources": W.get("weights_sources", {}),
         "diarization_embedder": diar_embedder,
         "denoiser": gate,
         "segmentation_vad": seg_vad,

@@ -100,7 +100,9 @@ def synthetic_whisper_state_dict(dims: WhisperDims, seed: int = 0, gain: float =
 
 def find_whisper_checkpoint(model_size: str = "small.en", cache_dir: Optional[str] = None):
     """Return (dims, state_dict) from `<cache_dir>/whisper/<size>.pt` (+ the `whisper-ft` overlay the
-    reference applies, back/api.py:671-692) or None when no checkpoint is present."""
+    reference applies, back/api.py:671-692) or None when no checkpoint is present.  Overlay semantics are those of
+    `load_state_dict(strict=False)` as the reference runs it: unknown keys are ignored; a key whose shape does not match is not
+    copied (torch raises afterwards, the reference logs the error and keeps the model -- with every matching key already applied)."""
     cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
     path = os.path.join(cache_dir, "whisper", f"{model_size}.pt")
     if not os.path.exists(path):
@@ -114,10 +116,10 @@ def find_whisper_checkpoint(model_size: str = "small.en", cache_dir: Optional[st
     if os.path.exists(st_path):
         from safetensors.torch import load_file
         over = load_file(st_path, device="cpu")
-        sd.update({k: v.float() for k, v in over.items() if k in sd})  # strict=False semantics
+        sd.update({k: v.float() for k, v in over.items() if k in sd and sd[k].shape == v.shape})  # strict=False; a size mismatch is skipped
     elif os.path.exists(pt_path):
         over = torch.load(pt_path, map_location="cpu", weights_only=True)
-        sd.update({k: v.float() for k, v in over.items() if k in sd})
+        sd.update({k: v.float() for k, v in over.items() if torch.is_tensor(v) and k in sd and sd[k].shape == v.shape})
     return dims, sd
 
 
@@ -177,16 +179,20 @@ def synthetic_sepformer_state_dict(dims: SepDims, seed: int = 0) -> Dict[str, to
     return sd
 
 
-# ----------------------------------------------------------------------------------------------
-# pyannote-style speaker networks [UPSTREAM-RECALL]: SincNet front end, XVectorSincNet, PyanNet
-# ----------------------------------------------------------------------------------------------
-def find_sepformer_checkpoint(cache_dir: Optional[str] = None) -> Optional[Dict[str, torch.Tensor]]:
+def find_sepformer_checkpoint(cache_dir: Optional[str] = None, apply_ft_overlay: Optional[bool] = None) -> Optional[Dict[str, torch.Tensor]]:
     """SpeechBrain savedir layout the reference uses (back/api.py:713-717): `<cache>/resepformer/{encoder,masknet,decoder}.ckpt`,
-    each the state_dict of that module, then the fine-tune overlay `<cache>/resepformer-ft/` the reference applies with
-    `load_state_dict(strict=False)` when all of hyperparams.yaml / masknet.ckpt / encoder.ckpt / decoder.ckpt exist
-    (back/api.py:729-746).  Returns one flat dict with `encoder.` / `masknet.` / `decoder.` prefixes, or None when the
-    base checkpoint is absent.  Files are read with weights_only=True."""
+    each the state_dict of that module.  Returns one flat dict with `encoder.` / `masknet.` / `decoder.` prefixes, or None when
+    the base checkpoint is absent.  Files are read with weights_only=True.
+
+    The fine-tune overlay `<cache>/resepformer-ft/`: the reference calls
+    `self.separator.load_state_dict({'masknet': {...}, 'encoder': {...}, 'decoder': {...}}, strict=False)` (back/api.py:739-746).
+    Those three top-level keys name no parameter of the SpeechBrain module (its keys are `mods.<part>.<name>`), and strict=False
+    drops unexpected keys silently, so the reference KEEPS THE BASE WEIGHTS.  Default here = that effective behaviour (overlay
+    ignored).  `apply_ft_overlay=True` (or CCX_APPLY_RESEPFORMER_FT=1) applies the overlay tensor by tensor -- what the reference's
+    author evidently intended, and a deliberate deviation from what the reference does."""
     cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
+    if apply_ft_overlay is None:
+        apply_ft_overlay = os.environ.get("CCX_APPLY_RESEPFORMER_FT", "0") not in ("", "0")
     base = os.path.join(cache_dir, "resepformer")
     parts = ("encoder", "masknet", "decoder")
     if not all(os.path.exists(os.path.join(base, f"{p}.ckpt")) for p in parts):
@@ -196,7 +202,7 @@ def find_sepformer_checkpoint(cache_dir: Optional[str] = None) -> Optional[Dict[
         for k, v in torch.load(os.path.join(base, f"{p}.ckpt"), map_location="cpu", weights_only=True).items():
             sd[f"{p}.{k}"] = v.float()
     ft = os.path.join(cache_dir, "resepformer-ft")
-    if all(os.path.exists(os.path.join(ft, f)) for f in ("hyperparams.yaml", "masknet.ckpt", "encoder.ckpt", "decoder.ckpt")):
+    if apply_ft_overlay and all(os.path.exists(os.path.join(ft, f)) for f in ("hyperparams.yaml", "masknet.ckpt", "encoder.ckpt", "decoder.ckpt")):
         for p in parts:
             for k, v in torch.load(os.path.join(ft, f"{p}.ckpt"), map_location="cpu", weights_only=True).items():
                 if f"{p}.{k}" in sd and sd[f"{p}.{k}"].shape == v.shape:      # strict=False: unknown keys are ignored
@@ -322,3 +328,152 @@ def synthetic_pyannet_state_dict(n_classes: int = 7, seed: int = 0) -> Dict[str,
     sd["classifier.weight"] = torch.randn(n_classes, 128, generator=g) / math.sqrt(128)
     sd["classifier.bias"] = 0.1 * torch.randn(n_classes, generator=g)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# pyannote-side checkpoints and pipeline hyper-parameters (reference back/api.py:776-792)
+# ----------------------------------------------------------------------------------------------
+# What the reference's three constructors pull from the Hugging Face hub [UPSTREAM-RECALL for the repository contents]:
+#   Inference("pyannote/embedding")                            -> pyannote/embedding/pytorch_model.bin            (XVectorSincNet)
+#   Pipeline.from_pretrained("pyannote/voice-activity-detection", cache_dir=<cache>/vad)
+#        -> config.yaml {pipeline.params.segmentation: pyannote/segmentation, params: onset/offset/min_duration_on/off}
+#        -> pyannote/segmentation/pytorch_model.bin                                                               (PyanNet, 3 classes)
+#   Pipeline.from_pretrained("pyannote/speaker-diarization-3.1", cache_dir=<cache>/speaker-diarization)
+#        -> config.yaml {params.clustering: method/min_cluster_size/threshold, params.segmentation.min_duration_off}
+#        -> pyannote/segmentation-3.0/pytorch_model.bin (PyanNet, 7 powerset classes), pyannote/wespeaker-voxceleb-resnet34-LM
+# A pytorch_model.bin is a Lightning checkpoint: {"state_dict": {...}, "hyper_parameters": ..., "pyannote.audio": ...}.
+PYANNOTE_MODELS = {
+    "xvector": ("pyannote/embedding", ("embedding",)),
+    "pyannet_vad": ("pyannote/segmentation", ("vad",)),
+    "pyannet_diar": ("pyannote/segmentation-3.0", ("speaker-diarization",)),
+    "resnet34": ("pyannote/wespeaker-voxceleb-resnet34-LM", ("speaker-diarization",)),
+}
+PYANNOTE_PIPELINES = {
+    "vad": ("pyannote/voice-activity-detection", "vad"),
+    "diarization": ("pyannote/speaker-diarization-3.1", "speaker-diarization"),
+}
+# defaults = the published config.yaml values as recalled; a config.yaml found on disk overrides them
+VAD_DEFAULTS = dict(onset=0.767, offset=0.377, min_duration_on=0.136, min_duration_off=0.067)
+DIAR_DEFAULTS = dict(threshold=0.7045654963945799, min_cluster_size=12, min_duration_off=0.0, method="centroid")
+
+
+def _hub_roots(cache_dir: str, subdirs) -> list:
+    roots = [os.path.join(cache_dir, s) for s in subdirs] + [cache_dir]
+    for env, tail in (("PYANNOTE_CACHE", ""), ("HF_HOME", "hub"), ("HUGGINGFACE_HUB_CACHE", ""), ("HF_HUB_CACHE", "")):
+        v = os.environ.get(env)
+        if v:
+            roots.append(os.path.join(v, tail) if tail else v)
+    home = os.path.expanduser("~")
+    roots += [os.path.join(home, ".cache", "torch", "pyannote"), os.path.join(home, ".cache", "huggingface", "hub")]
+    return roots
+
+
+def _hub_file(roots, repo: str, filenames) -> Optional[str]:
+    """First existing file among: the hub cache layout `<root>/models--<org>--<name>/snapshots/<rev>/<file>`, a plain checkout
+    `<root>/<org>/<name>/<file>` or `<root>/<name>/<file>`."""
+    import glob
+    org, name = repo.split("/")
+    for root in roots:
+        for fn in filenames:
+            cands = sorted(glob.glob(os.path.join(root, f"models--{org}--{name}", "snapshots", "*", fn)))
+            cands += [os.path.join(root, org, name, fn), os.path.join(root, name, fn)]
+            for c in cands:
+                if os.path.isfile(c):
+                    return c
+    return None
+
+
+class CheckpointRefused(RuntimeError):
+    """The weights-only loader would not read a file (it holds pickled objects beyond tensors and plain containers)."""
+
+
+def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
+    """Tensors of a checkpoint file WITHOUT executing anything from it: safetensors, or torch.load(weights_only=True) of either
+    a plain state_dict or a Lightning checkpoint ({"state_dict": ...}).  Raises CheckpointRefused when the safe loader refuses
+    the file (pyannote's published pytorch_model.bin files carry pickled task specifications; convert them once with
+    `torch.save(ckpt["state_dict"], path)` or to safetensors in an environment that has pyannote.audio)."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return {k: v.float() for k, v in load_file(path, device="cpu").items()}
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:           # pickle.UnpicklingError: unsupported global ...
+        raise CheckpointRefused(f"{path}: the weights-only loader refused this file ({type(e).__name__}: {str(e)[:200]})") from e
+    if isinstance(ck, dict) and isinstance(ck.get("state_dict"), dict):
+        ck = ck["state_dict"]
+    if not isinstance(ck, dict):
+        raise CheckpointRefused(f"{path}: not a state_dict")
+    return {k: v.float() if torch.is_floating_point(v) else v for k, v in ck.items() if torch.is_tensor(v)}
+
+
+def _conform(kind: str, sd: Dict[str, torch.Tensor], schema: Dict[str, torch.Tensor], path: str) -> Dict[str, torch.Tensor]:
+    """Keep exactly the tensors the kernels take (names + shapes of the architecture built here); fail loudly on a missing key or
+    a wrong shape -- a silently half-loaded network would run on noise."""
+    out = {}
+    for k, ref in schema.items():
+        if k not in sd:
+            raise ValueError(f"{path}: {kind} checkpoint lacks '{k}' (not the architecture built here)")
+        if tuple(sd[k].shape) != tuple(ref.shape):
+            if sd[k].numel() == ref.numel():
+                out[k] = sd[k].reshape(ref.shape)
+                continue
+            raise ValueError(f"{path}: '{k}' has shape {tuple(sd[k].shape)}, expected {tuple(ref.shape)}")
+        out[k] = sd[k]
+    return out
+
+
+def find_pyannote_checkpoint(kind: str, cache_dir: Optional[str] = None, log=None) -> Optional[Dict[str, torch.Tensor]]:
+    """State dict of one of the pyannote-side networks (`kind` in PYANNOTE_MODELS) from the places the reference's loaders
+    leave them (hub cache under MODEL_CACHE_DIR/<embedding|vad|speaker-diarization>, PYANNOTE_CACHE, HF_HOME) or None when no
+    usable file exists.  A file the weights-only loader refuses is reported through `log` and skipped."""
+    cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
+    repo, subdirs = PYANNOTE_MODELS[kind]
+    path = _hub_file(_hub_roots(cache_dir, subdirs), repo, ("model.safetensors", "pytorch_model.bin", "pytorch_model.pt"))
+    if path is None:
+        return None
+    try:
+        sd = load_state_dict_file(path)
+    except CheckpointRefused as e:
+        (log or print)(f"[ccx weights] {e}; using synthetic weights for {kind}")
+        return None
+    schema = {"xvector": synthetic_xvector_state_dict, "resnet34": synthetic_resnet34_state_dict,
+              "pyannet_vad": lambda: synthetic_pyannet_state_dict(3), "pyannet_diar": lambda: synthetic_pyannet_state_dict(7)}[kind]()
+    return _conform(kind, sd, schema, path)
+
+
+def find_pipeline_config(which: str, cache_dir: Optional[str] = None) -> Dict[str, object]:
+    """Hyper-parameters of `pyannote/voice-activity-detection` (which="vad") or `pyannote/speaker-diarization-3.1`
+    (which="diarization") from the pipeline's config.yaml when it is on disk (yaml.safe_load), else the recalled defaults.
+    The returned dict says where the values came from (`source`)."""
+    import yaml
+    cache_dir = cache_dir or os.environ.get("MODEL_CACHE_DIR", "models")
+    repo, sub = PYANNOTE_PIPELINES[which]
+    out: Dict[str, object] = dict(VAD_DEFAULTS if which == "vad" else DIAR_DEFAULTS)
+    out["source"] = "defaults"
+    path = _hub_file(_hub_roots(cache_dir, (sub,)), repo, ("config.yaml",))
+    if path is None:
+        return out
+    with open(path, "r", encoding="utf-8") as f:
+        cfg = yaml.safe_load(f) or {}
+    params = cfg.get("params") or {}
+    if which == "vad":
+        for k in ("onset", "offset", "min_duration_on", "min_duration_off"):
+            if k in params:
+                out[k] = float(params[k])
+    else:
+        cl = params.get("clustering") or {}
+        if "threshold" in cl:
+            out["threshold"] = float(cl["threshold"])
+        if "min_cluster_size" in cl:
+            out["min_cluster_size"] = int(cl["min_cluster_size"])
+        if "method" in cl:
+            out["method"] = str(cl["method"])
+        seg = params.get("segmentation") or {}
+        if "min_duration_off" in seg:
+            out["min_duration_off"] = float(seg["min_duration_off"])
+        if out["method"] != "centroid":
+            raise ValueError(f"{path}: clustering method '{out['method']}' is not implemented (only centroid linkage, the 3.1 default)")
+    pp = (cfg.get("pipeline") or {}).get("params") or {}
+    out["models"] = {k: v for k, v in pp.items() if isinstance(v, str)}
+    out["source"] = path
+    return out

@@ -74,9 +74,13 @@ def test_sepformer_checkpoint_layout_and_overlay(tmp_path):
     torch.save({"conv1d.weight": torch.full_like(sd["encoder.conv1d.weight"], 2.0), "not_a_key": torch.zeros(1)}, ft / "encoder.ckpt")
     torch.save({}, ft / "masknet.ckpt")
     torch.save({}, ft / "decoder.ckpt")
-    assert torch.equal(find_sepformer_checkpoint(str(tmp_path))["encoder.conv1d.weight"], sd["encoder.conv1d.weight"].float())
+    assert torch.equal(find_sepformer_checkpoint(str(tmp_path), apply_ft_overlay=True)["encoder.conv1d.weight"], sd["encoder.conv1d.weight"].float())
     (ft / "hyperparams.yaml").write_text("# present\n")
-    over = find_sepformer_checkpoint(str(tmp_path))
+    # default = the reference's EFFECTIVE behaviour: its load_state_dict({'masknet': .., 'encoder': .., 'decoder': ..}, strict=False)
+    # matches no parameter name, so the base weights stay (back/api.py:739-746)
+    same = find_sepformer_checkpoint(str(tmp_path))
+    assert torch.equal(same["encoder.conv1d.weight"], sd["encoder.conv1d.weight"].float())
+    over = find_sepformer_checkpoint(str(tmp_path), apply_ft_overlay=True)      # the intended overlay, behind an explicit switch
     assert float(over["encoder.conv1d.weight"].mean()) == 2.0 and "encoder.not_a_key" not in over
     assert find_sepformer_checkpoint(str(tmp_path / "absent")) is None
 
@@ -91,7 +95,90 @@ def test_whisper_checkpoint_layout_and_overlay(tmp_path):
     d, got = find_whisper_checkpoint("small.en", str(tmp_path))
     assert d.n_audio_state == 64 and torch.equal(got["decoder.ln.bias"], sd["decoder.ln.bias"])
     (tmp_path / "whisper-ft").mkdir()
-    save_file({"decoder.ln.bias": torch.ones(64), "extra.key": torch.zeros(2)}, str(tmp_path / "whisper-ft" / "model.safetensors"))
+    save_file({"decoder.ln.bias": torch.ones(64), "extra.key": torch.zeros(2), "encoder.conv1.weight": torch.zeros(8, 8)},
+              str(tmp_path / "whisper-ft" / "model.safetensors"))
     _, got = find_whisper_checkpoint("small.en", str(tmp_path))
     assert float(got["decoder.ln.bias"].mean()) == 1.0 and "extra.key" not in got
+    assert torch.equal(got["encoder.conv1.weight"], sd["encoder.conv1.weight"])      # a wrong-shaped overlay tensor is not copied
     assert find_whisper_checkpoint("small.en", str(tmp_path / "absent")) is None
+
+
+class _Spec:
+    """Stands in for pyannote.audio.core.task.Specifications (a pickled custom object inside the published checkpoints)."""
+
+
+def _hub(tmp_path, sub, repo, rev="abc123"):
+    org, name = repo.split("/")
+    d = tmp_path / sub / f"models--{org}--{name}" / "snapshots" / rev
+    d.mkdir(parents=True)
+    return d
+
+
+def test_pyannote_checkpoints_and_pipeline_configs_from_the_hub_cache_layout(tmp_path, monkeypatch):
+    """The three pyannote-side constructors of the reference (back/api.py:776-792) leave Lightning checkpoints
+    (`pytorch_model.bin` = {"state_dict": ...}) and pipeline `config.yaml` files in hub-cache directories.  Written here in
+    that layout with seeded tensors: the loaders must find them, return exactly the tensors, read the hyper-parameters, and
+    `build_state_dicts` must use them instead of synthetic weights."""
+    from clearconverse_amd import weights as W
+    from clearconverse_amd.models import build_state_dicts
+    monkeypatch.setenv("MODEL_CACHE_DIR", str(tmp_path))
+    for env in ("PYANNOTE_CACHE", "HF_HOME", "HUGGINGFACE_HUB_CACHE", "HF_HUB_CACHE"):
+        monkeypatch.delenv(env, raising=False)
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
+    assert W.find_pyannote_checkpoint("xvector") is None and W.find_pipeline_config("vad")["source"] == "defaults"
+
+    xv = W.synthetic_xvector_state_dict(seed=21)
+    extra = dict(xv); extra["sincnet.conv1d.0.filterbank.window_"] = torch.zeros(125)          # upstream buffers the kernels do not take
+    torch.save({"state_dict": extra, "pytorch-lightning_version": "1.6.5", "hyper_parameters": {"sample_rate": 16000}},
+               _hub(tmp_path, "embedding", "pyannote/embedding") / "pytorch_model.bin")
+    seg3 = W.synthetic_pyannet_state_dict(3, seed=22)
+    torch.save({"state_dict": seg3}, _hub(tmp_path, "vad", "pyannote/segmentation") / "pytorch_model.bin")
+    seg7 = W.synthetic_pyannet_state_dict(7, seed=23)
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in seg7.items()}, str(_hub(tmp_path, "speaker-diarization", "pyannote/segmentation-3.0") / "model.safetensors"))
+    rn = W.synthetic_resnet34_state_dict(seed=24)
+    torch.save(rn, _hub(tmp_path, "speaker-diarization", "pyannote/wespeaker-voxceleb-resnet34-LM") / "pytorch_model.bin")    # plain state_dict
+    (_hub(tmp_path, "vad", "pyannote/voice-activity-detection") / "config.yaml").write_text(
+        "pipeline:\n  name: pyannote.audio.pipelines.VoiceActivityDetection\n  params:\n    segmentation: pyannote/segmentation\n"
+        "params:\n  onset: 0.5\n  offset: 0.25\n  min_duration_on: 0.1\n  min_duration_off: 0.2\n")
+    (_hub(tmp_path, "speaker-diarization", "pyannote/speaker-diarization-3.1") / "config.yaml").write_text(
+        "version: 3.1.0\npipeline:\n  name: pyannote.audio.pipelines.SpeakerDiarization\n  params:\n    clustering: AgglomerativeClustering\n"
+        "    embedding: pyannote/wespeaker-voxceleb-resnet34-LM\n    segmentation: pyannote/segmentation-3.0\n"
+        "params:\n  clustering:\n    method: centroid\n    min_cluster_size: 9\n    threshold: 0.61\n  segmentation:\n    min_duration_off: 0.05\n")
+
+    got = W.find_pyannote_checkpoint("xvector")
+    assert set(got) == set(xv) and all(torch.equal(got[k], xv[k]) for k in xv)
+    for kind, want in (("pyannet_vad", seg3), ("pyannet_diar", seg7), ("resnet34", rn)):
+        got = W.find_pyannote_checkpoint(kind)
+        assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), kind
+    vad = W.find_pipeline_config("vad")
+    assert (vad["onset"], vad["offset"], vad["min_duration_on"], vad["min_duration_off"]) == (0.5, 0.25, 0.1, 0.2)
+    assert vad["models"]["segmentation"] == "pyannote/segmentation" and vad["source"].endswith("config.yaml")
+    di = W.find_pipeline_config("diarization")
+    assert (di["threshold"], di["min_cluster_size"], di["min_duration_off"], di["method"]) == (0.61, 9, 0.05, "centroid")
+    sds = build_state_dicts(None, whisper_dims=W.WhisperDims.mini(1, 64), sep_dims=SepDims(n_layers=1))
+    assert sds["weights_sources"]["xvector"] == "checkpoint" and sds["weights_sources"]["resnet34"] == "checkpoint"
+    assert torch.equal(sds["pyannet_vad"]["classifier.weight"], seg3["classifier.weight"]) and sds["vad_params"]["onset"] == 0.5
+    assert sds["diarization_params"]["threshold"] == 0.61
+
+
+def test_pyannote_loader_fails_loudly_on_wrong_architecture_and_reports_refused_files(tmp_path, monkeypatch):
+    from clearconverse_amd import weights as W
+    monkeypatch.setenv("MODEL_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
+    bad = W.synthetic_pyannet_state_dict(7, seed=1)
+    del bad["lstm.weight_hh_l3_reverse"]
+    torch.save({"state_dict": bad}, _hub(tmp_path, "speaker-diarization", "pyannote/segmentation-3.0") / "pytorch_model.bin")
+    with pytest.raises(ValueError, match="lacks 'lstm.weight_hh_l3_reverse'"):
+        W.find_pyannote_checkpoint("pyannet_diar")
+    # a checkpoint carrying a pickled custom object (as pyannote's published files do): the weights-only loader refuses it, nothing
+    # from the file is executed, the refusal is reported and the caller falls back
+    d = _hub(tmp_path, "embedding", "pyannote/embedding")
+    torch.save({"state_dict": {}, "pyannote.audio": {"specifications": _Spec()}}, d / "pytorch_model.bin")
+    said = []
+    assert W.find_pyannote_checkpoint("xvector", log=said.append) is None
+    assert said and "refused" in said[0]
+    with pytest.raises(ValueError, match="not implemented"):
+        (_hub(tmp_path, "speaker-diarization", "pyannote/speaker-diarization-3.1") / "config.yaml").write_text(
+            "params:\n  clustering:\n    method: average\n    min_cluster_size: 12\n    threshold: 0.7\n")
+        W.find_pipeline_config("diarization")
