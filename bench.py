@@ -193,7 +193,7 @@ def main():
         # every VAD (51 x 5 s) / diarization (21 x 10 s) window of the rank's clips goes through the segmentation net in ONE launch group
         models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0, state_dicts=sds,
                              seg_max_crops=52 * B + 16, seg_max_seconds=300.0 * B, emb_max_crops=44 * B,
-                             resnet_max_chunks=21 * B, whisper_instances=2 if args.schedule == "pipelined" else 1)
+                             resnet_max_chunks=21 * B, whisper_instances=2 if args.schedule == "pipelined" else 1, max_audio_seconds=30.0)
         del sds
         sd = None
         bp = BatchPipeline(models, whisper_group=args.whisper_group, sample_len=args.sample_len)

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "ccx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ccx_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
     "ccx_peak_normalize": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _vp]),
+    "ccx_resample_sinc": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "ccx_enc_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ccx_whisper_create": (_i, [_vp, C.POINTER(WhisperDims), _i, C.POINTER(_vp)]),
     "ccx_whisper_destroy": (None, [_vp]),
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "ccx_specgate_create": (_i, [_vp, _i64, _i, _i, C.POINTER(_vp)]),
     "ccx_specgate_destroy": (None, [_vp]),
     "ccx_specgate_reduce": (_i, [_vp, _vp, _i64, _ip, _i, _f, _vp, _vp]),
+    "ccx_specgate_reduce_long": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

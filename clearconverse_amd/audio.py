@@ -68,19 +68,15 @@ def write_wav(path: str, audio: np.ndarray, sr: int = SAMPLE_RATE) -> None:
         w.writeframes(pcm.tobytes())
 
 
-def resample_poly_sinc(x: np.ndarray, orig_sr: int, new_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
-    """Band-limited sinc (Hann-windowed) resampling of [channels, n] -- the algorithm of
-    torchaudio.transforms.Resample with its default arguments [UPSTREAM-RECALL], which the reference
-    applies when a file is not 16 kHz (back/api.py:824-830).  Host-side numpy: K1 is outside the
-    timed hot path for the 16 kHz benchmark clips."""
+def sinc_resample_kernel(orig_sr: int, new_sr: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Polyphase table of `torchaudio.transforms.Resample(orig_sr, new_sr)` with its default arguments (sinc_interp_hann)
+    [UPSTREAM-RECALL], which the reference applies when a file is not 16 kHz (back/api.py:824-830).  Built in float64 and cast
+    to float32 as upstream does.  Returns (kernT [taps, n] float32 -- TRANSPOSED for the device kernel --, width, o, n) with
+    o / n the two rates over their gcd and taps = 2 * width + o.  A table, like the mel filterbank: all arithmetic on the audio
+    runs in libccx (csrc/resample.hip)."""
     import math
-    x = np.asarray(x, dtype=np.float64)
-    if x.ndim == 1:
-        x = x[None]
     g = math.gcd(int(orig_sr), int(new_sr))
     o, n = int(orig_sr) // g, int(new_sr) // g
-    if o == n:
-        return x.astype(np.float32)
     base = min(o, n) * rolloff
     width = math.ceil(lowpass_filter_width * o / base)
     idx = np.arange(-width, width + o, dtype=np.float64)[None, :] / o
@@ -88,14 +84,45 @@ def resample_poly_sinc(x: np.ndarray, orig_sr: int, new_sr: int, lowpass_filter_
     t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
     window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
     tp = t * math.pi
-    kern = np.where(tp == 0, 1.0, np.sin(tp) / np.where(tp == 0, 1.0, tp)) * window * (base / o)   # [n, 2*width + o]
-    length = x.shape[-1]
-    xp = np.pad(x, ((0, 0), (width, width + o)))
-    n_frames = (xp.shape[-1] - kern.shape[1]) // o + 1
-    sl = np.lib.stride_tricks.sliding_window_view(xp, kern.shape[1], axis=-1)[:, ::o][:, :n_frames]   # [c, frames, taps]
-    y = np.einsum("cft,nt->cfn", sl, kern).reshape(x.shape[0], -1)
-    target = int(math.ceil(n * length / o))
-    return y[:, :target].astype(np.float32)
+    kern = np.where(tp == 0, 1.0, np.sin(tp) / np.where(tp == 0, 1.0, tp)) * window * (base / o)   # [n, taps]
+    return np.ascontiguousarray(kern.T.astype(np.float32)), width, o, n
+
+
+class SincResampler:
+    """Drop-in for the `torchaudio.transforms.Resample(orig_freq=, new_freq=)` object the reference keeps in `self.resampler`
+    (back/api.py:824-830; it re-creates it when `.orig_freq` differs).  Calling it with a [channels, time] or [time] tensor
+    returns the resampled tensor ON THE GPU; the arithmetic is `ccx_resample_sinc` (hand-written HIP, no CPU fallback)."""
+
+    def __init__(self, orig_freq: int, new_freq: int = SAMPLE_RATE, device: int = 0, ctx=None):
+        import torch
+        from . import _lib
+        if not torch.cuda.is_available():
+            raise _lib.CcxError("SincResampler needs a ROCm GPU: the HIP path has no CPU fallback")
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self.ctx = ctx or _lib.Context(device)
+        self.device = torch.device("cuda", device)
+        kT, self.width, self.o, self.n = sinc_resample_kernel(self.orig_freq, self.new_freq)
+        self.kernT = torch.from_numpy(kT).to(self.device)
+
+    def __call__(self, signal):
+        import math
+        import torch
+        from . import _lib
+        x = torch.as_tensor(signal)
+        squeeze = x.dim() == 1
+        x = (x[None] if squeeze else x).to(self.device, torch.float32).contiguous()
+        if self.orig_freq == self.new_freq:
+            return x[0] if squeeze else x
+        B, T = x.shape
+        n_out = int(math.ceil(self.n * T / self.o))
+        y = torch.empty(B, max(n_out, 1), device=self.device, dtype=torch.float32)
+        ni = torch.full((B,), T, dtype=torch.int32, device=self.device)
+        no = torch.full((B,), n_out, dtype=torch.int32, device=self.device)
+        self.ctx.check(self.ctx.lib.ccx_resample_sinc(self.ctx.handle, x.data_ptr(), x.shape[1], ni.data_ptr(), B, self.o, self.n, self.width,
+                                                      self.kernT.data_ptr(), y.data_ptr(), y.shape[1], no.data_ptr(), n_out,
+                                                      _lib.current_stream_ptr()), "ccx_resample_sinc")
+        y = y[:, :n_out]
+        return y[0] if squeeze else y
 
 
 # 30 s activity schedule of the synthetic benchmark clips (SURVEY.md section 8d)

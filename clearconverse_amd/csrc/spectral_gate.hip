@@ -46,21 +46,25 @@ __device__ __forceinline__ void fft1024(float2* s, const float2* __restrict__ tw
 
 // One block per (frame, clip).  pad = 0 (noise profile pass) or SG_PAD (signal pass).
 // Writes dB = 20 log10(|X| + eps) and optionally X.
+// `origin` (optional): clip c is the window [origin[c], origin[c] + n_samples[c]) of a longer signal of `total` samples that
+// starts at y + c * stride (chunks of one long file: stride 0); samples outside the window but inside the signal are READ
+// (noisereduce pads a chunk with its real neighbours, zeros only beyond the ends of the signal).
 __global__ __launch_bounds__(256) void sg_stft_kernel(const float* __restrict__ y, long stride, const int* __restrict__ n_samples,
                                                       const int* __restrict__ n_frames, int pad, const float2* __restrict__ tw,
                                                       const float* __restrict__ win, float* __restrict__ db, float2* __restrict__ X,
-                                                      long clip_stride_rows) {
+                                                      long clip_stride_rows, const long* __restrict__ origin, long total) {
   __shared__ float2 s[SG_N];
   const int clip = blockIdx.y, fr = blockIdx.x, tid = threadIdx.x;
   if (fr >= n_frames[clip]) return;
-  const int n = n_samples[clip];
-  const float* x = y + (long)clip * stride;
+  const long org = origin ? origin[clip] : 0;
+  const long n = origin ? total - org : (long)n_samples[clip];     // readable samples counted from the window start
+  const float* x = y + (long)clip * stride + org;
   const long base = (long)fr * SG_HOP - SG_N / 2 - pad;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int i = tid + 256 * r;
     const long o = base + i;
-    const float v = (o >= 0 && o < n) ? x[o] * win[i] * (1.0f / 512.0f) : 0.f;
+    const float v = (o >= -org && o < n) ? x[o] * win[i] * (1.0f / 512.0f) : 0.f;
     s[__brev((unsigned)i) >> 22] = make_float2(v, 0.f);
   }
   __syncthreads();
@@ -181,11 +185,16 @@ __global__ __launch_bounds__(256) void sg_istft_kernel(const float2* __restrict_
 
 // overlap-add, divide by the overlap-added squared window, crop the zero padding away
 __global__ void sg_overlap_add_kernel(const float* __restrict__ td, const int* __restrict__ n_samples, const int* __restrict__ n_frames,
-                                      long clip_stride_rows, const float* __restrict__ win, float* __restrict__ out, long stride) {
+                                      long clip_stride_rows, const float* __restrict__ win, float* __restrict__ out, long stride,
+                                      const long* __restrict__ origin, long span) {
   const int clip = blockIdx.y;
   const long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = n_samples[clip];
-  if (o >= stride) return;
+  if (origin) {                                    // chunk of a long signal: only the chunk's own samples are written
+    if (o >= n) return;
+    out += origin[clip];
+  }
+  if (o >= span) return;
   float v = 0.f;
   if (o < n) {
     const int nf = n_frames[clip];
@@ -220,6 +229,7 @@ struct ccx_specgate {
   float *db = nullptr, *tmp = nullptr, *td = nullptr, *thresh = nullptr, *floorv = nullptr;
   float2* X = nullptr;
   int *n_dev = nullptr, *nf_noise = nullptr, *nf_sig = nullptr;
+  long* origin = nullptr;          // reduce_long: first sample of each chunk
 };
 
 namespace {
@@ -307,14 +317,14 @@ int ccx_specgate_reduce(ccx_specgate* g, const float* y, int64_t stride, const i
   const long rows = g->rows;
   // noise profile from the clip itself
   hipLaunchKernelGGL(sg_stft_kernel, dim3(max_fn, B), dim3(256), 0, st, y, (long)stride, g->n_dev, g->nf_noise, 0, g->tw, g->win, g->db,
-                     (float2*)nullptr, rows);
+                     (float2*)nullptr, rows, (const long*)nullptr, 0L);
   CCX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), B), dim3(256), 0, st, g->db, g->nf_noise, rows, 1.5f, g->thresh,
                      (float*)nullptr);
   CCX_CHECK_LAUNCH(ctx);
   // padded signal pass
   hipLaunchKernelGGL(sg_stft_kernel, dim3(max_fs, B), dim3(256), 0, st, y, (long)stride, g->n_dev, g->nf_sig, SG_PAD, g->tw, g->win, g->db,
-                     g->X, rows);
+                     g->X, rows, (const long*)nullptr, 0L);
   CCX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), B), dim3(256), 0, st, g->db, g->nf_sig, rows, 0.f, (float*)nullptr,
                      g->floorv);
@@ -328,8 +338,77 @@ int ccx_specgate_reduce(ccx_specgate* g, const float* y, int64_t stride, const i
   hipLaunchKernelGGL(sg_istft_kernel, dim3(max_fs, B), dim3(256), 0, st, g->X, g->nf_sig, rows, g->tw, g->win, g->td);
   CCX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(sg_overlap_add_kernel, dim3(ccx_cdiv((int)stride, 256), B), dim3(256), 0, st, g->td, g->n_dev, g->nf_sig, rows, g->win,
-                     out, (long)stride);
+                     out, (long)stride, (const long*)nullptr, (long)stride);
   CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+// One signal of any length the workspace holds: noisereduce's chunked path (chunk_size 600000, padding 30000).  The threshold
+// comes from the WHOLE signal (its noise statistics are taken over y itself); every 600000-sample chunk is then gated on its
+// own -- padded with 30000 real neighbour samples on each side (zeros beyond the ends of the signal), its dB floor (max - 80)
+// taken per chunk -- and only the chunk's own samples are written.  Chunks are processed as the "clips" of the batched kernels.
+int ccx_specgate_reduce_long(ccx_specgate* g, const float* y, int64_t n, float prop_decrease, float* out, void* stream_) {
+  if (!g) return CCX_ERR_ARG;
+  ccx_ctx* ctx = g->ctx;
+  hipStream_t st = (hipStream_t)stream_;
+  CCX_REQUIRE(ctx, y && out && n >= 1, "specgate_reduce_long: bad arguments");
+  const long CH = 600000;
+  const long R = g->rows * g->max_clips;                 // frame rows of the workspace
+  const long nfn = 1 + n / SG_HOP;
+  const long rows_c = (CH + 2 * SG_PAD) / SG_HOP + 2;
+  CCX_REQUIRE(ctx, nfn <= R && rows_c <= R, "specgate_reduce_long: %ld samples need %ld frame rows, the workspace holds %ld (max_samples x max_clips)", (long)n, nfn > rows_c ? nfn : rows_c, R);
+  CCX_REQUIRE(ctx, n < (1L << 31) - CH, "specgate_reduce_long: signal too long");
+  if (!g->origin) GTRY(galloc(g, &g->origin, (size_t)g->max_clips));
+  // ---- threshold from the whole signal (one "clip" that owns all rows) ----
+  const int n_i = (int)n, nfn_i = (int)nfn;
+  CCX_HIP(ctx, hipMemcpyAsync(g->n_dev, &n_i, 4, hipMemcpyHostToDevice, st));
+  CCX_HIP(ctx, hipMemcpyAsync(g->nf_noise, &nfn_i, 4, hipMemcpyHostToDevice, st));
+  CCX_HIP(ctx, hipStreamSynchronize(st));
+  hipLaunchKernelGGL(sg_stft_kernel, dim3(nfn_i, 1), dim3(256), 0, st, y, 0L, g->n_dev, g->nf_noise, 0, g->tw, g->win, g->db,
+                     (float2*)nullptr, R, (const long*)nullptr, 0L);
+  CCX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), 1), dim3(256), 0, st, g->db, g->nf_noise, R, 1.5f, g->thresh, (float*)nullptr);
+  CCX_CHECK_LAUNCH(ctx);
+  // ---- chunks, as many at a time as the workspace holds ----
+  const long nchunks = (n + CH - 1) / CH;
+  long per = R / rows_c;
+  if (per > g->max_clips) per = g->max_clips;
+  for (int k = 1; k < per && k < nchunks; k++)           // every chunk clip reads the signal's threshold row
+    CCX_HIP(ctx, hipMemcpyAsync(g->thresh + (size_t)k * SG_LD, g->thresh, SG_LD * 4, hipMemcpyDeviceToDevice, st));
+  for (long c0 = 0; c0 < nchunks; c0 += per) {
+    const int nb = (int)((nchunks - c0 < per) ? nchunks - c0 : per);
+    std::vector<int> len(nb), nfs(nb);
+    std::vector<long> org(nb);
+    int max_fs = 0, max_len = 0;
+    for (int k = 0; k < nb; k++) {
+      org[k] = (c0 + k) * CH;
+      len[k] = (int)((n - org[k] < CH) ? n - org[k] : CH);
+      nfs[k] = 1 + (len[k] + 2 * SG_PAD) / SG_HOP;
+      max_fs = nfs[k] > max_fs ? nfs[k] : max_fs;
+      max_len = len[k] > max_len ? len[k] : max_len;
+    }
+    CCX_HIP(ctx, hipMemcpyAsync(g->n_dev, len.data(), nb * 4, hipMemcpyHostToDevice, st));
+    CCX_HIP(ctx, hipMemcpyAsync(g->nf_sig, nfs.data(), nb * 4, hipMemcpyHostToDevice, st));
+    CCX_HIP(ctx, hipMemcpyAsync(g->origin, org.data(), nb * 8, hipMemcpyHostToDevice, st));
+    CCX_HIP(ctx, hipStreamSynchronize(st));
+    hipLaunchKernelGGL(sg_stft_kernel, dim3(max_fs, nb), dim3(256), 0, st, y, 0L, g->n_dev, g->nf_sig, SG_PAD, g->tw, g->win, g->db, g->X,
+                       rows_c, (const long*)g->origin, (long)n);
+    CCX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sg_bin_stats_kernel, dim3(ccx_cdiv(SG_BINS, 32), nb), dim3(256), 0, st, g->db, g->nf_sig, rows_c, 0.f, (float*)nullptr,
+                       g->floorv);
+    CCX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sg_mask_freq_kernel, dim3(ccx_cdiv(SG_BINS, 128), max_fs, nb), dim3(128), 0, st, g->db, g->floorv, g->thresh, g->nf_sig,
+                       rows_c, prop_decrease, g->ff, g->tmp);
+    CCX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sg_mask_time_apply_kernel, dim3(ccx_cdiv(SG_BINS, 128), max_fs, nb), dim3(128), 0, st, g->tmp, g->nf_sig, rows_c, g->ft,
+                       g->X);
+    CCX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sg_istft_kernel, dim3(max_fs, nb), dim3(256), 0, st, g->X, g->nf_sig, rows_c, g->tw, g->win, g->td);
+    CCX_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(sg_overlap_add_kernel, dim3(ccx_cdiv(max_len, 256), nb), dim3(256), 0, st, g->td, g->n_dev, g->nf_sig, rows_c, g->win,
+                       out, 0L, (const long*)g->origin, (long)max_len);
+    CCX_CHECK_LAUNCH(ctx);
+  }
   return CCX_OK;
 }
 

@@ -50,9 +50,20 @@ class SpectralGate:
                                                         out[b0:b0 + nb].data_ptr(), _lib.current_stream_ptr()), "ccx_specgate_reduce")
         return out
 
+    def reduce_long(self, y: torch.Tensor, prop_decrease: float) -> torch.Tensor:
+        """One 1-D signal of any length (GPU tensor): noisereduce's chunked path -- threshold from the whole signal, 600000-sample
+        chunks with 30000 samples of context (ccx_specgate_reduce_long).  Whole conversations go through this."""
+        assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 1 and y.is_contiguous()
+        out = torch.empty_like(y)
+        self.ctx.check(self.lib.ccx_specgate_reduce_long(self.handle, y.data_ptr(), int(y.numel()), float(prop_decrease), out.data_ptr(),
+                                                         _lib.current_stream_ptr()), "ccx_specgate_reduce_long")
+        return out
+
     def __call__(self, y, sr: int = 16000, prop_decrease: float = 1.0) -> np.ndarray:
         if int(sr) != self.sr:
             raise _lib.CcxError(f"SpectralGate was built for {self.sr} Hz, got {sr}")
         x = np.ascontiguousarray(np.asarray(y, dtype=np.float32).reshape(1, -1))
         d = torch.from_numpy(x).to(self.device)
+        if x.shape[1] > self.max_samples:
+            return self.reduce_long(d[0], prop_decrease).cpu().numpy()
         return self.reduce_batch(d, [x.shape[1]], prop_decrease)[0].cpu().numpy()

@@ -56,7 +56,7 @@ def build_state_dicts(config=None, whisper_dims: Optional[WhisperDims] = None, s
     }
 
 
-def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
+def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 600.0,
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
                 seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None,

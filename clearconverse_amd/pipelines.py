@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .audio import read_wav, resample_poly_sinc
+from .audio import SincResampler, read_wav
 
 SR = 16000
 FRAME_STEP = 270 / SR          # SincNet: stride 10 x three maxpool3
@@ -74,7 +74,7 @@ def load_mono_16k(path_or_wave):
     if x.ndim > 1:
         x = x.mean(axis=0)
     if sr != SR:
-        x = resample_poly_sinc(x[None], sr, SR)[0]
+        return SincResampler(sr, SR)(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))     # K1 on the device, stays resident
     return np.ascontiguousarray(x, dtype=np.float32)
 
 

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import intervals as iv
-from .audio import read_wav, resample_poly_sinc, write_wav
+from .audio import SincResampler, read_wav, write_wav
 
 log = logging.getLogger("clearconverse_amd")
 
@@ -156,7 +156,11 @@ class EnhancedAudioProcessor:
         if sig.shape[0] > 1:
             sig = sig.mean(axis=0, keepdims=True)
         if sr != sr_t:
-            sig = resample_poly_sinc(sig, sr, sr_t)
+            # K1 on the device (csrc/resample.hip); the object is kept and re-created when the input rate changes, as the
+            # reference does with torchaudio.transforms.Resample (back/api.py:825-830)
+            if self.resampler is None or self.resampler.orig_freq != sr:
+                self.resampler = SincResampler(sr, sr_t)
+            sig = self.resampler(torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float32))).cpu().numpy()
         x = sig.reshape(-1).astype(np.float32)
         x = self._denoise(x, self.config.noise_reduction_amount)
         x = x / (np.max(np.abs(x)) + 1e-8)

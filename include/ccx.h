@@ -64,6 +64,15 @@ int ccx_gather_rows(ccx_ctx* ctx, const int64_t* src_ptrs_dev, const int* lens_d
 int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t stride, const int* n_samples_dev, int B,
                        float eps, void* stream);
 
+/* K1: `torchaudio.transforms.Resample(orig_freq=sample_rate, new_freq=16000)(signal)` (reference back/api.py:824-830) with
+ * torchaudio's default arguments.  orig / new_ are the two rates divided by their gcd, width = ceil(6 * orig / (min(orig, new_) * 0.99)),
+ * kernT_dev the polyphase table TRANSPOSED, [2 * width + orig][new_] f32 (built by the caller exactly as upstream builds it:
+ * clearconverse_amd/audio.py::sinc_resample_kernel).  x [B, stride_in] f32 rows of n_in_dev[b] samples -> y [B, stride_out] rows
+ * of n_out_dev[b] = ceil(new_ * n_in / orig) samples; max_out = the largest of them.  All pointers are device pointers. */
+int ccx_resample_sinc(ccx_ctx* ctx, const float* x_dev, int64_t stride_in, const int* n_in_dev, int B, int orig, int new_,
+                      int width, const float* kernT_dev, float* y_dev, int64_t stride_out, const int* n_out_dev, int max_out,
+                      void* stream);
+
 /* Non-causal attention, head_dim 64 (Whisper encoder).  q,k: [B*H, Spad, 64] bf16 with rows >= S
  * zero; vt: [B*H, 64, Spad] bf16; o: [B*S, H*64] bf16.  Softmax scale 1/8 (= 64^-0.25 on q and k). */
 int ccx_enc_attention(ccx_ctx* ctx, const void* q_dev, const void* k_dev, const void* vt_dev, void* o_dev,
@@ -216,6 +225,11 @@ void ccx_specgate_destroy(ccx_specgate* g);
 /* y_dev [B, stride] f32, n_samples host [B] -> out_dev [B, stride] f32 (samples past n_samples[b] are zero) */
 int ccx_specgate_reduce(ccx_specgate* g, const float* y_dev, int64_t stride, const int* n_samples, int B,
                         float prop_decrease, float* out_dev, void* stream);
+/* One signal of ANY length (device pointers): noisereduce's chunked path for inputs beyond its chunk_size of 600000 samples --
+ * threshold from the whole signal, then each 600000-sample chunk gated with 30000 samples of real context on either side
+ * (the reference passes whole files to nr.reduce_noise, back/api.py:832-833).  Capacity: n / 256 + 1 <= frame rows of the
+ * workspace = (max_samples + 60000) / 256 + 2 per clip x max_clips.  y_dev and out_dev must not overlap. */
+int ccx_specgate_reduce_long(ccx_specgate* g, const float* y_dev, int64_t n, float prop_decrease, float* out_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,10 +23,17 @@ def test_spectral_gate_knob_limits():
     assert e[0] >= e[1] >= e[2] > 0.0
 
 
-def test_spectral_gate_rejects_multi_chunk_input():
-    import pytest
-    with pytest.raises(NotImplementedError):
-        G.reduce_noise(np.zeros(600001, np.float32))
+def test_spectral_gate_multi_chunk_equals_single_chunk_away_from_the_seams(monkeypatch):
+    """The chunked path (threshold from the whole signal, chunks with real-neighbour padding): with a small chunk size the result
+    must equal the one-chunk result except near chunk seams, where each chunk's own dB floor / mask smoothing ends."""
+    x = synthetic_clip(3, 6.0)
+    one = G.reduce_noise(x, 16000, prop_decrease=0.8)
+    monkeypatch.setattr(G, "CHUNK", 40000)
+    monkeypatch.setattr(G, "PADDING", 4000)
+    many = G.reduce_noise(x, 16000, prop_decrease=0.8)
+    assert many.shape == one.shape
+    rel = float(np.linalg.norm(many - one) / np.linalg.norm(one))
+    assert rel < 0.05, rel              # same threshold; only the per-chunk dB floor (max - 80) can differ
 
 
 def test_pyannet_frame_counts_and_determinism():

@@ -146,7 +146,7 @@ def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
     sds = build_state_dicts(None, seed=0)
     assert sds["whisper_dims"]["n_audio_layer"] == 12 and sds["sep_dims"]["n_layers"] == 8      # full size
     models = load_models(None, 0, whisper_batch=192, ctx=ccx_ctx, seed=0, state_dicts=sds, seg_max_crops=52 * B + 16,
-                         seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B)
+                         seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B, max_audio_seconds=30.0)
     del sds
     bp = BatchPipeline(models, whisper_group=192, sample_len=sample_len)
     audio = torch.from_numpy(np.stack([synthetic_clip(i, 30.0) for i in range(B)])).cuda().contiguous()

@@ -97,3 +97,22 @@ def test_pipelined_schedule_equals_sequential(ccx_ctx):
         m[k].close()
     for w in m["whisper_models"]:
         w.close()
+
+
+def test_processor_run_on_a_45_second_wav(models, tmp_path):
+    """A conversation longer than one Whisper window / one spectral-gate chunk through EnhancedAudioProcessor.run: load_audio gates
+    the whole file by the chunked path (2 chunks), the pipelines slide over it, and a turn longer than 30 s is transcribed window
+    by window.  (The reference handles arbitrary lengths: noisereduce chunks, whisper seeks.)"""
+    from clearconverse_amd.processor import Config, EnhancedAudioProcessor
+    clip = np.concatenate([synthetic_clip(3, 30.0), 0.8 * synthetic_clip(4, 30.0)[: 16000 * 15]])
+    path = str(tmp_path / "long.wav")
+    write_wav(path, clip)
+    p = EnhancedAudioProcessor(Config(temperature=0.0), load_models_immediately=False, model_loader=lambda cfg, dev: models)
+    p._initialize_models()
+    audio, sr = p.load_audio(path)
+    assert audio.shape == (1, 45 * 16000) and abs(float(audio.abs().max()) - 1.0) < 1e-4
+    out = p.run(path, output_dir=str(tmp_path / "out"))
+    assert isinstance(out, tuple) and len(out) == 3
+    # a single 40 s turn straight through the Whisper call surface: two windows
+    res = models["whisper_model"].transcribe(audio[0, : 16000 * 40].cpu().numpy(), initial_prompt="This is a conversation between two people.")
+    assert len({s["seek"] for s in res["segments"]}) >= 2

@@ -44,3 +44,23 @@ def test_batch_equals_single_and_pads_zero(ccx_ctx):
         assert np.all(out[1, 64000:] == 0)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("seconds", [35.0, 45.0, 80.3])
+def test_long_signal_chunked_path_matches_oracle(ccx_ctx, seconds):
+    """Signals beyond the batch capacity / noisereduce's 600000-sample chunk (reference: whole files go through nr.reduce_noise,
+    back/api.py:832): threshold from the whole signal, chunks with 30000 samples of real context.  35 s = one chunk through the
+    long entry, 45 s = two chunks, 80.3 s = three (the last one short)."""
+    from clearconverse_amd.denoise import SpectralGate
+    g = SpectralGate(max_samples=480000, max_clips=4, ctx=ccx_ctx)
+    try:
+        n = int(seconds * 16000)
+        x = np.concatenate([synthetic_clip(20 + i, 30.0) * (1.0 if i % 2 == 0 else 0.4) for i in range(3)])[:n]
+        got = g(x, 16000, 0.5)
+        ref = reduce_noise(x, 16000, 0.5)
+        assert got.shape == ref.shape
+        assert _rel(got, ref) < 2e-3, _rel(got, ref)
+        for seam in range(600000, n, 600000):              # no discontinuity at a chunk seam
+            assert _rel(got[seam - 2000:seam + 2000], ref[seam - 2000:seam + 2000]) < 5e-3
+    finally:
+        g.close()

@@ -13,7 +13,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 B = 32
 ctx = _lib.Context(0)
 models = load_models(None, 0, whisper_batch=192, ctx=ctx, seed=0, state_dicts=build_state_dicts(None, seed=0), seg_max_crops=52 * B + 16,
-                     seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B, whisper_instances=2)
+                     seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B, whisper_instances=2, max_audio_seconds=30.0)
 bp = BatchPipeline(models, whisper_group=192, sample_len=224)
 audio = torch.from_numpy(np.stack([synthetic_clip(i, 30.0) for i in range(B)])).cuda().contiguous()
 bp.run_pinned(audio); bp.run_pinned_pipelined([audio] * 2)
