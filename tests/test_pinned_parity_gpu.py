@@ -5,7 +5,8 @@
 (b) `ccx_peak_normalize` through the C ABI against x / (max|x| + eps) (/root/reference/back/api.py:834 and 350-351).
 (c) BASELINE configs[3] at FULL size (32 x 30 s clips, small.en, full-depth SepFormer, whisper group 192, hipGraph decode lanes):
     the oracle cannot run that in seconds, so it is checked through a size-independent property -- a clip's records do not depend
-    on its batch mates: clips run alone give bit-identical tokens / similarities.
+    on its batch mates: clips run alone give identical tokens, bit-identical embeddings and separated waveforms, similarities
+    equal to 1 ulp and log-probabilities equal to 4e-4 relative (reasons next to the assertions).
 
 Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages; about 4x the worst deviation measured on MI355X, which is given
 in brackets): gated + normalised clip rel-L2 1e-5 [2e-7]; profile embeddings rel-L2 1e-2 [2.5e-3]; cosine similarities abs 2e-4
@@ -155,9 +156,11 @@ def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
     assert all(len(x["tokens"]) == sample_len or len(x["tokens"]) < sample_len for x in full["records"])
     for b in (0, 13, 31):
         one = bp.run_pinned(audio[b:b + 1].contiguous(), debug=True)
-        assert one["sims"] == full["sims"][2 * b:2 * b + 2], b
+        # similarities: torch's row-wise cosine reduction picks its strategy by the shape of the batch -> equal to 1 ulp, not bitwise
+        assert np.allclose(one["sims"], full["sims"][2 * b:2 * b + 2], rtol=0, atol=3e-7), b
         rows = [i for i, ow in enumerate(full["window_owner"]) if ow // 2 == b]
-        assert torch.equal(one["window_sims_full"], full["window_sims_full"][rows]), b
+        assert torch.allclose(one["window_sims_full"], full["window_sims_full"][rows], rtol=0, atol=3e-7), b
+        assert torch.equal(one["profile_embeds"][0], full["profile_embeds"][b]), b      # the embeddings themselves are bit-identical
         assert one["pick"] == full["pick"][4 * b:4 * b + 4], b
         for k in range(4):
             n = one["region_len"][k]
@@ -165,8 +168,11 @@ def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
         idx = [2 * b, 2 * b + 1] + [2 * B + 4 * b + k for k in range(4)]
         for j, i in enumerate(idx):
             assert one["records"][j]["tokens"] == full["records"][i]["tokens"], (b, j)
-            # identical tokens; the log-probabilities differ in the last fp32 digits because the cross attention of a 64-row lane
-            # is cut into 3 key ranges and that of a 6-row batch into 6 (different merge order of the online softmax)
-            assert abs(one["records"][j]["sum_logprob"] - full["records"][i]["sum_logprob"]) < 5e-3, (b, j)
+            # identical tokens; the log-probabilities agree to ~4e-4 relative only: a 64-row lane runs the whole key range of a
+            # (sequence, head) in one block, a 6-row batch cuts it into 6 split-KV partials -- a different merge order of the
+            # online softmax, and where the fp32 attention output sits at a bf16 rounding boundary one element of the next GEMV's
+            # input moves by 2^-9
+            lp = full["records"][i]["sum_logprob"]
+            assert abs(one["records"][j]["sum_logprob"] - lp) < 2e-3 * max(1.0, abs(lp)), (b, j)
     for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
         models[m].close()
