@@ -303,9 +303,9 @@ def main():
 
         def roof_entry(name, cnt_, fl, by, ms, where):
             pmc = {}
-            pf = ROOT / "profiles" / "r01_pmc_traffic.json"
-            if pf.exists():
-                pmc = json.loads(pf.read_text()).get(name, {})
+            pfs = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))       # the newest round's counter passes
+            if pfs:
+                pmc = json.loads(pfs[-1].read_text()).get(name, {})
             if name in MFMA_KERNELS:
                 ach = fl / (ms * 1e-3) / 1e12
                 return dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS, unit="TFLOP/s",

@@ -787,8 +787,19 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     pend_n = ccx_dec_linear_ksplit(K, DEPI_PARTIAL);
     return CCX_OK;
   };
+  // diagnostic only (results are garbage): CCX_ABLATE=cross drops the cross attention launches, =chain everything else of a layer
+  static const int ablate = [] { const char* e = getenv("CCX_ABLATE"); return !e ? 0 : (!strcmp(e, "cross") ? 1 : (!strcmp(e, "chain") ? 2 : 0)); }();
   for (int l = 0; l < d.n_text_layer; l++) {
     const DecLayer& L = w->dec[l];
+    if (ablate == 2 && B > 16) {
+      DecAttnParams ap;
+      memset(&ap, 0, sizeof(ap));
+      ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
+      ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
+      ap.lds_pad = w->cross_lds_pad; ap.stream_mode = w->cross_stream ? 1 : 0;
+      TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
+      continue;
+    }
     // LN + QKV, k/v appended to the self cache at pos[b]
     {
       DecLinearParams ex;
@@ -810,7 +821,9 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
     ap.lds_pad = w->cross_lds_pad;
     ap.stream_mode = (w->cross_stream && B > 16) ? 1 : 0;
-    if (B > 16) {
+    if (ablate == 1 && B > 16) {
+      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+    } else if (B > 16) {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
       if (ns > 1) TRY(ccx_launch_dec_combine(ctx, part_o, part_ml, ns, dattn, B, H, stream));
       TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
