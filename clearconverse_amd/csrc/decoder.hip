@@ -80,22 +80,34 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   int nks = kz1 - ks0;
   nks = nks < 0 ? 0 : (nks > per_w ? per_w : nks);
 
-  // bias of this thread's output column (the epilogue walks e = tid + 256 i, and 256 % BN == 0): loaded up front so
-  // that the epilogue has no dependent memory round trip of its own
-  float bias_v = 0.f;
-  {
-    const int nb_ = n0 + tid % BN;
-    if (p.bias && blockIdx.z == 0 && nb_ < p.N) bias_v = p.bias[nb_];
-  }
-
-  // DEPI_SELF_QKV appends k/v at pos[row]: the rows this thread stores (e = tid + 256 i -> row e / BN) are known now
-  constexpr int EPI_ITERS = (BN * MROWS + 255) / 256;
+  // Epilogue ownership: a thread finishes QUADS of 4 consecutive output columns of one row.  Quad qd = ((i * MT + j) * 64 + ln)
+  // is exactly the f32x4 that lane ln of every wave holds for tile (i, j): row 16 j + (ln & 15), columns 16 i + 4 (ln >> 4) .. + 3.
+  // The four waves' partial sums of a quad are therefore four ds_read_b128 at consecutive-lane addresses (conflict-free; the
+  // former one-column-per-thread walk read single floats 64 apart: 4-way bank conflicts, 60 % of the kernel's LDS cycles).
+  constexpr int QUADS = NT * MT * 64;
+  constexpr int EPI_ITERS = (QUADS + 255) / 256;
+  // bias of this thread's columns and, for DEPI_SELF_QKV, the cache position of its rows: loaded up front so that the epilogue
+  // has no dependent memory round trip of its own
+  float4 bias_v[EPI_ITERS];
   int pos_v[EPI_ITERS];
-  if (EPI == DEPI_SELF_QKV) {
 #pragma unroll
-    for (int i = 0; i < EPI_ITERS; i++) {
-      const int m_ = m0 + (tid + 256 * i) / BN;
-      pos_v[i] = p.pos[m_ < p.M ? m_ : p.M - 1];
+  for (int it = 0; it < EPI_ITERS; it++) {
+    const int qd = tid + 256 * it;
+    const int ln = qd & 63, tj = (qd >> 6) % MT, ti = (qd >> 6) / MT;
+    const int n_ = n0 + 16 * ti + 4 * (ln >> 4);
+    bias_v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && blockIdx.z == 0 && qd < QUADS) {
+      if (n_ + 3 < p.N) bias_v[it] = *(const float4*)(p.bias + n_);
+      else {
+        if (n_ < p.N) bias_v[it].x = p.bias[n_];
+        if (n_ + 1 < p.N) bias_v[it].y = p.bias[n_ + 1];
+        if (n_ + 2 < p.N) bias_v[it].z = p.bias[n_ + 2];
+      }
+    }
+    pos_v[it] = 0;
+    if (EPI == DEPI_SELF_QKV) {
+      const int m_ = m0 + 16 * tj + (ln & 15);
+      pos_v[it] = p.pos[m_ < p.M ? m_ : p.M - 1];
     }
   }
 
@@ -287,34 +299,45 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 
 #pragma unroll
   for (int it = 0; it < EPI_ITERS; it++) {
-    const int e = tid + 256 * it;
-    if (e >= BN * MROWS) break;
-    const int nl = e % BN, r = e / BN;
-    const int n = n0 + nl, m = m0 + r;
+    const int qd = tid + 256 * it;
+    if (qd >= QUADS) break;
+    const int ln = qd & 63, j = (qd >> 6) % MT, i = (qd >> 6) / MT;
+    const int m = m0 + 16 * j + (ln & 15), n = n0 + 16 * i + 4 * (ln >> 4);
     if (n >= p.N || m >= p.M) continue;
-    const int i = nl >> 4, j = r >> 4;
-    const int ln = (r & 15) + 16 * ((nl & 15) >> 2), rg = nl & 3;
-    float v = 0.f;
+    f32x4 v = *(const f32x4*)(red + (((0 * NT + i) * MT + j) * 64 + ln) * 4);
 #pragma unroll
-    for (int w = 0; w < 4; w++) v += red[(((w * NT + i) * MT + j) * 64 + ln) * 4 + rg];
-    v += bias_v;
+    for (int w = 1; w < 4; w++) v += *(const f32x4*)(red + (((w * NT + i) * MT + j) * 64 + ln) * 4);      // same order as before: w = 0..3
+    v[0] += bias_v[it].x; v[1] += bias_v[it].y; v[2] += bias_v[it].z; v[3] += bias_v[it].w;
+    const bool full = n + 3 < p.N;       // N is a multiple of 4 everywhere but a guard costs nothing
     if (EPI == DEPI_BF16_GELU) {
-      ((bf16_t*)p.out)[(long)m * p.ldo + n] = f32_to_bf16(gelu_erf(v));
-    } else if (EPI == DEPI_PARTIAL) {
-      ((float*)p.out)[(long)blockIdx.z * p.pend_stride + (long)m * p.ldo + n] = v;
-    } else if (EPI == DEPI_F32) {
-      ((float*)p.out)[(long)m * p.ldo + n] = v;
+      bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+      if (full) {
+        uint2 pk;
+        pk.x = pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1]));
+        pk.y = pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]));
+        *(uint2*)o = pk;
+      } else {
+        for (int c = 0; c < 4 && n + c < p.N; c++) o[c] = f32_to_bf16(gelu_erf(v[c]));
+      }
+    } else if (EPI == DEPI_PARTIAL || EPI == DEPI_F32) {
+      float* o = (float*)p.out + (EPI == DEPI_PARTIAL ? (long)blockIdx.z * p.pend_stride : 0L) + (long)m * p.ldo + n;
+      if (full) *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+      else
+        for (int c = 0; c < 4 && n + c < p.N; c++) o[c] = v[c];
     } else if (EPI == DEPI_SELF_QKV) {
-      const int D = p.K;  // d_model
+      const int D = p.K;  // d_model (a multiple of 64: a quad never straddles q / k / v or two heads)
       if (n < D) {
-        ((float*)p.out)[(long)m * D + n] = v;
+        *(float4*)((float*)p.out + (long)m * D + n) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         const int which = (n >= 2 * D);
         const int nn = n - (which ? 2 * D : D);
         const int hh = nn >> 6, d = nn & 63;
         const int H = D >> 6;
         bf16_t* cache = which ? p.cache_v : p.cache_k;
-        cache[(((long)m * H + hh) * p.cache_T + pos_v[it]) * 64 + d] = f32_to_bf16(v);
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(cache + (((long)m * H + hh) * p.cache_T + pos_v[it]) * 64 + d) = pk;
       }
     }
   }
