@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--whisper-group", type=int, default=192, help="sequences decoded together in the pipeline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="one extra (untimed) step with a sync after every stage")
+    ap.add_argument("--decode-span", type=int, default=2,
+                    help="pipelined schedule: batches whose Whisper windows are encoded and decoded together (1 = one decode group per batch)")
     ap.add_argument("--schedule", choices=("pipelined", "sequential"), default="pipelined",
                     help="pipeline workload: overlap batch i's Whisper decode with batch i+1's front end (default) or run each batch start to finish")
     args = ap.parse_args()
@@ -191,6 +193,8 @@ def main():
             torch.cuda.synchronize()
             bcast_ms = (time.perf_counter() - tb) * 1e3
         # every VAD (51 x 5 s) / diarization (21 x 10 s) window of the rank's clips goes through the segmentation net in ONE launch group
+        if args.schedule == "pipelined" and args.decode_span > 1:
+            args.whisper_group = max(args.whisper_group, 6 * B * args.decode_span)
         models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0, state_dicts=sds,
                              seg_max_crops=52 * B + 16, seg_max_seconds=300.0 * B, emb_max_crops=44 * B,
                              resnet_max_chunks=21 * B, whisper_instances=2 if args.schedule == "pipelined" else 1, max_audio_seconds=30.0)
@@ -219,7 +223,7 @@ def main():
         """k steps of the hot path; pipelined schedule: the k batches go through the software pipeline together (every batch
         is processed completely inside the call, the decode of batch i overlapping the front end of batch i + 1)."""
         if pipelined:
-            return bp.run_pinned_pipelined([audio] * k) if k > 0 else []
+            return bp.run_pinned_pipelined([audio] * k, span=args.decode_span) if k > 0 else []
         return [step() for _ in range(k)]
 
     torch.cuda.synchronize()
@@ -242,7 +246,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    seq_ms = None
+    seq_ms = span1_ms = None
+    if pipelined and args.decode_span > 1:
+        # the same pipeline with one decode group per batch, for comparison (untimed for `value`)
+        n1 = min(4, max(2, args.steps))
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        bp.run_pinned_pipelined([audio] * n1, span=1)
+        torch.cuda.synchronize()
+        span1_ms = (time.perf_counter() - ts) * 1e3 / n1
     if pipelined:
         # the sequential schedule of the same batch, for comparison (untimed for `value`)
         nseq = min(3, max(1, args.steps))
@@ -269,7 +281,8 @@ def main():
     # per-launch HIP events on, to get the average launch duration of the graph-resident kernels.
     probe_steps = 6
     wm = models["whisper_model"] if pipeline else model
-    Bd = min(args.whisper_group, 6 * B) if pipeline else B
+    span = args.decode_span if (pipeline and args.schedule == "pipelined") else 1
+    Bd = min(args.whisper_group, 6 * B * span) if pipeline else B
     os.environ["CCX_NO_GRAPH"] = "1"
     ctx.prof_enable(True)
     wm.decode_greedy([[rules.sot]] * Bd, sample_len=probe_steps)
@@ -277,7 +290,8 @@ def main():
     probe = ctx.prof_records()
     ctx.prof_enable(False)
     del os.environ["CCX_NO_GRAPH"]
-    decode_steps_per_step = (args.sample_len + 1) * ((6 * B + Bd - 1) // Bd if pipeline else 1)
+    # decode launches per pipeline step: a unit of `span` batches is decoded in ceil(6 B span / Bd) groups
+    decode_steps_per_step = (args.sample_len + 1) * (((6 * B * span + Bd - 1) // Bd) / span if pipeline else 1)
 
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -374,6 +388,14 @@ def main():
                                 "of batch i+1 (MFMA-bound) on a second stream, two Whisper instances alternating" if pipelined
                                 else "; sequential: each batch start to finish")
             cfg["batch_schedule"] = args.schedule
+            cfg["decode_span_batches"] = args.decode_span if pipelined else 1
+            if pipelined and args.decode_span > 1:
+                cfg["schedule"] += (f"; the Whisper windows of {args.decode_span} consecutive batches ({6 * B * args.decode_span} sequences) are encoded and "
+                                    "decoded as one group: with that many sequences per decode lane the latency-bound step chain hides under the "
+                                    "other lanes' HBM-bound cross attention")
+            if span1_ms is not None:
+                cfg["pipelined_span1_ms_per_step"] = round(span1_ms, 3)
+                cfg["pipelined_span1_xrt"] = round(30.0 * B * world / (span1_ms * 1e-3), 2)
             if seq_ms is not None:
                 cfg["sequential_ms_per_step"] = round(seq_ms, 3)
                 cfg["sequential_xrt"] = round(30.0 * B * world / (seq_ms * 1e-3), 2)

@@ -219,12 +219,17 @@ class BatchPipeline:
 
 
     # ------------------------------------------------------------------ software-pipelined schedule
-    def run_pinned_pipelined(self, audios: Sequence[torch.Tensor], debug: bool = False) -> List[Dict[str, object]]:
+    def run_pinned_pipelined(self, audios: Sequence[torch.Tensor], debug: bool = False, span: int = 1) -> List[Dict[str, object]]:
         """The same work as [run_pinned(a) for a in audios], software-pipelined across batches: while the Whisper windows of
         batch i decode (HBM-bound cross attention + latency-bound chain, on the decode lanes' own high-priority streams, driven
         by a worker thread -- the C call releases the GIL), the front end and the encoder of batch i + 1 (MFMA-bound) run on a
         second stream.  Two Whisper instances (models["whisper_models"]) alternate, so an encode never overwrites cross-KV that
-        is still being decoded.  Results are identical to the sequential schedule: same kernels, same order per batch."""
+        is still being decoded.  Results are identical to the sequential schedule: same kernels, same order per batch.
+
+        `span` > 1: the Whisper windows of `span` consecutive batches are encoded and decoded TOGETHER (one decode group of
+        span x 6 x B sequences).  The decode step is a latency-bound chain of ~150 small kernels per lane plus the HBM-bound
+        cross attention; a lane's chain hides under the other lanes' cross attention only when that cross attention lasts as
+        long as the chain, i.e. with enough sequences per lane ("Decode lanes")."""
         from concurrent.futures import ThreadPoolExecutor
         whs = self.m.get("whisper_models") or [self.m["whisper_model"]]
         if len(whs) < 2:
@@ -256,12 +261,18 @@ class BatchPipeline:
         slot_busy = [None] * len(whs)
         unit = 0
         with ThreadPoolExecutor(max_workers=1) as ex, torch.cuda.stream(self._front_stream):
-            for audio in audios:
+            held = []                           # front states waiting for the rest of their span
+            for ai, audio in enumerate(audios):
                 tf0 = time.perf_counter()
-                st = self._front(audio, False, debug)
+                held.append(self._front(audio, False, debug))
                 if trace is not None:
                     self._front_stream.synchronize(); trace.append(("front", unit, tf0, time.perf_counter()))
-                crops, prompts = st["whisper_crops"], st["whisper_prompts"]
+                if len(held) < max(1, span) and ai + 1 < len(audios):
+                    continue
+                # one Whisper unit for the windows of every held batch
+                crops = [c for h_ in held for c in h_["whisper_crops"]]
+                prompts = [q for h_ in held for q in h_["whisper_prompts"]]
+                bounds = np.cumsum([0] + [len(h_["whisper_crops"]) for h_ in held]).tolist()
                 futs, pids = [], []
                 for i0 in range(0, len(crops), grp):
                     k = unit % len(whs)
@@ -284,15 +295,20 @@ class BatchPipeline:
                     slot_busy[k] = fut
                     futs.append((fut, buf))                        # buf stays referenced until its kernels have run
                     unit += 1
-                pending.append((st, futs, pids))
-                # hand finished batches over as soon as their decodes are done (keeps at most two batches of state alive)
+                pending.append((held, bounds, futs, pids))
+                held = []
+                # hand finished units over as soon as their decodes are done (keeps at most two units of state alive)
                 while len(pending) > 2:
-                    st0, f0, p0 = pending.pop(0)
-                    out.append(self._finish(st0, [r for f, _ in f0 for r in f.result()], p0 if debug else None, False))
-            for st0, f0, p0 in pending:
-                out.append(self._finish(st0, [r for f, _ in f0 for r in f.result()], p0 if debug else None, False))
+                    out += self._finish_unit(*pending.pop(0), debug)
+            for u in pending:
+                out += self._finish_unit(*u, debug)
             self._front_stream.synchronize()
         return out
+
+    def _finish_unit(self, held, bounds, futs, pids, debug) -> List[Dict[str, object]]:
+        recs = [r for f, _ in futs for r in f.result()]
+        return [self._finish(st, recs[bounds[k]:bounds[k + 1]], pids[bounds[k]:bounds[k + 1]] if debug else None, False)
+                for k, st in enumerate(held)]
 
 
 def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:
