@@ -8,7 +8,6 @@ enum { DEPI_BF16_GELU = 1, DEPI_PARTIAL = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4 };
 struct DecLinearParams {
   int M, N, K;
   const bf16_t* W; long ldw;      // [N][K]
-  int w_cached;                   // 1: default-policy weight loads (may stay in the Infinity Cache); 0: non-temporal
   const float* bias;              // [N] or null
   // activation sources
   const float* x;                 // ACT_LN: [M][K] f32 residual stream (before the pending partials)

@@ -52,11 +52,7 @@ __global__ void dec_embed_kernel(const float* __restrict__ tok_emb, const float*
 // grid.z = K split, so 4.7 MB matrices spread over 192 blocks instead of 48) and the NEXT
 // LayerNorm prologue folds them in (x_eff = x_in + sum partials), block (0,*,0) writing x_eff to
 // the other residual buffer (ping-pong: no block may see a half-updated stream).
-// W_NT: weights by non-temporal loads (a matrix that is streamed once per step and should not displace anything) or by
-// default-policy loads (layer weights that can stay in the 256 MB Infinity Cache from one decode step to the next: the
-// 12 layers' matrices are 198 MB in bf16, and the only other big per-step streams -- cross-attention K/V and the 80 MB tied
-// embedding of the logits -- are read non-temporally).
-template <int MT, int NT, int KMAX, int ACT, int EPI, bool W_NT>
+template <int MT, int NT, int KMAX, int ACT, int EPI>
 __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MROWS = 16 * MT;
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
       const int kk = k < nks ? k : 0;  // clamp instead of branching: keeps the loads back to back
-      wf[i][k] = W_NT ? __builtin_nontemporal_load((const bf16x8*)(wr + 512 * kk)) : *(const bf16x8*)(wr + 512 * kk);
+      wf[i][k] = __builtin_nontemporal_load((const bf16x8*)(wr + 512 * kk));
     }
   }
   bf16x8 af[MT][KMAX];
@@ -456,8 +452,8 @@ int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, i
   return CCX_OK;
 }
 
-template <int MT, int NT, int KMAX, int ACT, int EPI, bool W_NT>
-static int launch_dec_linear_inst2(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
+template <int MT, int NT, int KMAX, int ACT, int EPI>
+static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
   const int MROWS = 16 * MT, BN = 16 * NT;
   size_t act_bytes = (ACT == ACT_BF16) ? 0 : ccx_align((size_t)MROWS * (p.K + 8) * 2, 16);
   size_t red_bytes = (size_t)4 * NT * MT * 64 * 4 * 4;
@@ -466,7 +462,7 @@ static int launch_dec_linear_inst2(ccx_ctx* ctx, const DecLinearParams& p, int k
   CCX_REQUIRE(ctx, ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), 4) <= KMAX, "dec_linear: K=%d / split %d exceeds the prefetch depth %d", p.K, ksplit, KMAX);
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && lds > attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI, W_NT>,
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = 160 * 1024;
   }
@@ -478,16 +474,10 @@ static int launch_dec_linear_inst2(ccx_ctx* ctx, const DecLinearParams& p, int k
                                      ", " + std::to_string(ACT) + ", " + std::to_string(EPI) + ">";
     ccx_prof_scope ps(ctx, stream, label.c_str(), 2.0 * p.M * (double)p.N * p.K,
                       2.0 * (double)p.N * p.K + 2.0 * p.M * ((double)p.K + p.N));
-    hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI, W_NT>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI>), grid, dim3(256), lds, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
-}
-
-template <int MT, int NT, int KMAX, int ACT, int EPI>
-static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
-  if (p.w_cached) return launch_dec_linear_inst2<MT, NT, KMAX, ACT, EPI, false>(ctx, p, ksplit, stream);
-  return launch_dec_linear_inst2<MT, NT, KMAX, ACT, EPI, true>(ctx, p, ksplit, stream);
 }
 
 template <int NT, int ACT, int EPI>
@@ -520,17 +510,6 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
   const int ksplit = ccx_dec_linear_ksplit(p.K, epi);
   CCX_REQUIRE(ctx, epi == DEPI_PARTIAL || ksplit == 1, "dec_linear: K=%d needs a split-K (partial) epilogue", p.K);
   CCX_REQUIRE(ctx, epi != DEPI_PARTIAL || p.pend_stride >= (long)p.M * p.ldo, "dec_linear: pend_stride too small");
-  // LayerNorm prologue with more than 16 rows: a block owns ONE 16-row panel and 64 output columns (grid.y = row panels), so
-  // it normalises only its own 16 rows (under the flight of its weight loads) -- no stand-alone LayerNorm launch, and no block
-  // redoes the LayerNorm of all rows.  Same arithmetic as the 16-row path (K split over the 4 waves in the same order).
-  if (act == ACT_LN && p.M > 16) {
-    const int need = ccx_cdiv(p.K / 32, 4);
-    CCX_REQUIRE(ctx, need <= 6, "dec_linear: LN row panels need K <= 768");
-    if (epi == DEPI_SELF_QKV) return launch_dec_linear_inst<1, 4, 6, ACT_LN, DEPI_SELF_QKV>(ctx, p, 1, stream);
-    if (epi == DEPI_F32) return launch_dec_linear_inst<1, 4, 6, ACT_LN, DEPI_F32>(ctx, p, 1, stream);
-    if (epi == DEPI_BF16_GELU) return launch_dec_linear_inst<1, 4, 6, ACT_LN, DEPI_BF16_GELU>(ctx, p, 1, stream);
-    return ccx_fail(ctx, CCX_ERR_ARG, "dec_linear: unsupported LN row-panel epilogue %d", epi);
-  }
   // wide-N layers (logits) use 64-row weight panels per block, narrow ones 16 to spread over more CUs
   const bool wide = p.N >= 8192;
   if (act == ACT_BF16 && epi == DEPI_F32 && wide) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
@@ -846,14 +825,14 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
     const int np_need = p.pos ? 0 : ((ccx_cdiv(ccx_cdiv(p.T, nsplit), 4) + 31) / 32);
     if (p.stream_mode && !p.pos && np_need <= 12) {
       const int pad = p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0;
-#define CCX_CROSS_STREAM_LAUNCH(F, NP)                                                                                       \
+#define CCX_CROSS_STREAM_LAUNCH(F, ...)                                                                                      \
   do {                                                                                                                       \
     static bool attr_ = false;                                                                                               \
     if (!attr_) {                                                                                                            \
-      CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_cross_stream_kernel<F, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+      CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_cross_stream_kernel<F, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
       attr_ = true;                                                                                                          \
     }                                                                                                                        \
-    hipLaunchKernelGGL((dec_cross_stream_kernel<F, NP>), grid, dim3(256), pad, stream, p);                                   \
+    hipLaunchKernelGGL((dec_cross_stream_kernel<F, __VA_ARGS__>), grid, dim3(256), pad, stream, p);                         \
   } while (0)
       if (final_out) {
         if (np_need <= 4) CCX_CROSS_STREAM_LAUNCH(true, 4); else if (np_need <= 6) CCX_CROSS_STREAM_LAUNCH(true, 6); else CCX_CROSS_STREAM_LAUNCH(true, 12);

@@ -110,7 +110,7 @@ struct ccx_whisper {
   int max_prompt_cap = 0, sample_cap = 0;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
   // stream (stream capture is illegal there)
-  std::map<std::array<int, 8>, hipGraphExec_t> graphs;
+  std::map<std::array<int, 9>, hipGraphExec_t> graphs;
   hipStream_t own_stream = nullptr;
   hipEvent_t own_event = nullptr;
   // decode lanes: disjoint row ranges of one batch stepping concurrently on their own streams, staggered so
@@ -124,6 +124,9 @@ struct ccx_whisper {
                                              // queue run strictly one after the other, so lanes are picked by a probe
   std::map<hipStream_t, std::vector<hipStream_t>> lane_sets;   // lane-0 stream -> streams that overlap with it and each other
   int* probe_sink = nullptr;
+  unsigned long long* stamps = nullptr;      // [kMaxLanes][kStampCap] diagnostic trace (CCX_DEC_STAMPS)
+  int* stamp_count = nullptr;                // [kMaxLanes]
+  static constexpr int kStampCap = 1 << 16;
   hipEvent_t lane_start[kMaxLanes] = {}, lane_poll[2][kMaxLanes] = {};
   int* poll_host = nullptr;                  // pinned [2][kMaxLanes]
 };
@@ -530,6 +533,10 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   }
   for (int i = 0; i < ccx_whisper::kLanePool; i++) CCX_HIP(w->ctx, hipStreamCreateWithPriority(&w->lane_pool[i], hipStreamNonBlocking, prio_greatest));
   TRY(dev_alloc(w, &w->probe_sink, (size_t)64, true));
+  if (getenv("CCX_DEC_STAMPS")) {
+    TRY(dev_alloc(w, &w->stamps, (size_t)ccx_whisper::kMaxLanes * ccx_whisper::kStampCap, true));
+    TRY(dev_alloc(w, &w->stamp_count, (size_t)ccx_whisper::kMaxLanes, true));
+  }
   CCX_HIP(w->ctx, hipHostMalloc((void**)&w->poll_host, 2 * ccx_whisper::kMaxLanes * sizeof(int), 0));
   w->finalized = true;
   return CCX_OK;
@@ -650,6 +657,16 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// ---- diagnostic time stamps (CCX_DEC_STAMPS=<file>, CCX_DEC_STAMP_LEVEL=1|2) ----
+// A one-thread kernel that appends the 100 MHz wall clock (s_memrealtime) and a tag to the lane's trace; captured into the step
+// graphs like any other node.  Level 1 brackets the cross attention of every layer (tags 1 / 2), level 2 also stamps after every
+// chain kernel (tag 16 + kernel index in the layer).  Perturbs what it measures (one more ~2 us node per stamp): level 1 adds 24
+// nodes to a step of ~150, and is what tools/decode_stamps.py reads.
+__global__ void dec_stamp_kernel(unsigned long long* trace, int* count, int cap, int tag) {
+  const int i = atomicAdd(count, 1);
+  if (i < cap) trace[i] = (__builtin_amdgcn_s_memrealtime() << 8) | (unsigned long long)(tag & 255);
+}
+
 // ---- lane stream selection ----
 // HIP multiplexes streams onto a handful of hardware queues, and streams that share a queue execute strictly one
 // after the other (tools/microbench_lanes2.hip: some pairs of 8 fresh streams take 2x, the others 1x).  The mapping
@@ -726,7 +743,7 @@ int cross_split(int B, int H, bool capped, bool lean = false) {
 // dx and dx2: out-proj / cross-out / FFN2 only write split-K partial slabs (pend) and the next LayerNorm
 // folds them in (decoder.hip).  `stagger`, if set, is recorded right before layer 0's cross attention.
 int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, int* n_done,
-             hipStream_t stream, hipEvent_t stagger = nullptr) {
+             hipStream_t stream, hipEvent_t stagger = nullptr, int lane_idx = 0) {
   ccx_ctx* ctx = w->ctx;
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
@@ -745,22 +762,20 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   float* part_ml = w->part_ml + ro * H * ccx_whisper::kCrossSplitMax * 2;
   int* pos = w->pos + b0;
   const long cross_off = ro * H * w->Spad * 64, self_off = ro * H * Tc * 64;
+  static const int stamp_level = [] { const char* e = getenv("CCX_DEC_STAMP_LEVEL"); return e ? atoi(e) : 1; }();
+  auto stamp = [&](int tag, int level) {
+    if (w->stamps && level <= stamp_level)
+      hipLaunchKernelGGL(dec_stamp_kernel, dim3(1), dim3(1), 0, stream, w->stamps + (size_t)lane_idx * ccx_whisper::kStampCap,
+                         w->stamp_count + lane_idx, ccx_whisper::kStampCap, tag);
+  };
   int pend_n = 0;
-  // CCX_DEC_W_CACHED=1: the layers' weight matrices by default-policy loads (Infinity Cache residency across steps)
-  static const int w_cached = [] { const char* e = getenv("CCX_DEC_W_CACHED"); return e ? atoi(e) : 0; }();
   auto ln_linear = [&](int epi, const bf16_t* W, const float* bias, int N, const float* g, const float* bta, void* out, long ldo,
                        DecLinearParams* extra) -> int {
     DecLinearParams lp;
     if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias; lp.out = out; lp.ldo = ldo;
-    lp.w_cached = w_cached;
     int rc;
-    // CCX_DEC_FUSE_LN=1: LayerNorm stays in the linear's prologue for every batch size (16-row panels, decoder.hip);
-    // 0 (default): more than 16 rows are normalised once by a stand-alone kernel.  Measured at 3 x 64 rows: fused 880.7 ms per
-    // pipeline step, stand-alone 871.9 -- the fused kernel needs the whole register file of its CU and lives longer, which costs
-    // more beside another lane's cross attention than the three launches it saves.
-    static const int fuse_ln = [] { const char* e = getenv("CCX_DEC_FUSE_LN"); return e ? atoi(e) : 0; }();
-    if (B > 16 && !(fuse_ln && D <= 768)) {
+    if (B > 16) {
       // many sequences: normalise ONCE in a stand-alone kernel instead of redundantly in every weight-panel block
       rc = ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, g, bta, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
       if (rc) return rc;
@@ -779,7 +794,6 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     DecLinearParams lp;
     memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = D; lp.K = K; lp.W = W; lp.ldw = K; lp.bias = bias; lp.act = a; lp.lda = K;
-    lp.w_cached = w_cached;
     lp.part_o = part_o; lp.part_ml = part_ml; lp.nsplit = ns;
     lp.out = pend; lp.ldo = D; lp.pend_stride = pstride;
     int rc = ccx_launch_dec_linear(ctx, act, DEPI_PARTIAL, lp, stream);
@@ -806,15 +820,19 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       memset(&ex, 0, sizeof(ex));
       ex.cache_k = L.selfK + self_off; ex.cache_v = L.selfV + self_off; ex.cache_T = Tc; ex.pos = pos;
       TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, dq, D, &ex));
+      stamp(16, 2);
     }
     DecAttnParams ap;
     memset(&ap, 0, sizeof(ap));
     ap.q = dq; ap.k = L.selfK + self_off; ap.v = L.selfV + self_off; ap.H = H; ap.kv_T = Tc; ap.pos = pos; ap.scale_log2e = scale_log2e;
     ap.out_bf16 = dattn;
     TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
+    stamp(17, 2);
     TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
+    stamp(18, 2);
     // cross attention
     TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
+    stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     memset(&ap, 0, sizeof(ap));
     ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
@@ -825,15 +843,19 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
     } else if (B > 16) {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
+      stamp(2, 1);
       if (ns > 1) TRY(ccx_launch_dec_combine(ctx, part_o, part_ml, ns, dattn, B, H, stream));
       TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+      stamp(19, 2);
     } else {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
       TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     }
     // MLP
     TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, dffn, F, nullptr));
+    stamp(20, 2);
     TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, dffn));
+    stamp(21, 2);
   }
   // resolve the last partials + final LN, then logits against the tied embedding
   TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, w->lnd_g, w->lnd_b, dxn, nullptr, B, D, 1e-5f, stream));
@@ -866,6 +888,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     sp.sample_cfg = w->sample_cfg; sp.row0 = b0; sp.sample = w->sampling ? 1 : 0;
     TRY(ccx_launch_dec_select(ctx, sp, B, stream));
   }
+  stamp(3, 1);       // end of the step
   return CCX_OK;
 }
 
@@ -1014,7 +1037,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   for (int i = 1; i < nl; i++) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->own_event, 0));
   auto step_lane = [&](int i, hipEvent_t stagger) -> int {
     const Lane& L = lanes[i];
-    return dec_step(w, L.b0, L.B, w->dlogits + (long)L.b0 * ld, ld, true, sample_len, max_prompt, w->n_done + i, L.s, stagger);
+    return dec_step(w, L.b0, L.B, w->dlogits + (long)L.b0 * ld, ld, true, sample_len, max_prompt, w->n_done + i, L.s, stagger, i);
   };
   // first step runs eagerly (also performs one-time kernel attribute setup outside of capture).  Lane i + 1
   // starts when lane i reaches its first cross attention, which sets the stagger the later steps keep.
@@ -1029,7 +1052,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 8> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream, i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;
@@ -1092,6 +1115,25 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   for (int i = 1; i < nl; i++) {
     CCX_HIP(ctx, hipEventRecord(w->lane_start[i], lanes[i].s));
     CCX_HIP(ctx, hipStreamWaitEvent(stream, w->lane_start[i], 0));
+  }
+  if (w->stamps) {
+    // append this decode's trace: one line per lane "lane <i> <n> <stamp> ..." (stamp = realtime << 8 | tag), then reset
+    CCX_HIP(ctx, hipStreamSynchronize(stream));
+    std::vector<int> cnt(ccx_whisper::kMaxLanes);
+    CCX_HIP(ctx, hipMemcpy(cnt.data(), w->stamp_count, cnt.size() * 4, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(getenv("CCX_DEC_STAMPS"), "a")) {
+      fprintf(f, "decode B %d lanes %d\n", B, nl);
+      for (int i = 0; i < nl; i++) {
+        const int n = cnt[i] < ccx_whisper::kStampCap ? cnt[i] : ccx_whisper::kStampCap;
+        std::vector<unsigned long long> buf(n);
+        CCX_HIP(ctx, hipMemcpy(buf.data(), w->stamps + (size_t)i * ccx_whisper::kStampCap, (size_t)n * 8, hipMemcpyDeviceToHost));
+        fprintf(f, "lane %d %d", i, n);
+        for (int k = 0; k < n; k++) fprintf(f, " %llu", buf[k]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    CCX_HIP(ctx, hipMemset(w->stamp_count, 0, ccx_whisper::kMaxLanes * 4));
   }
   std::vector<DecSeqState> st(B);
   std::vector<int> gen((size_t)B * sample_len);
