@@ -6,13 +6,12 @@ of the reference (Pipeline.from_pretrained("pyannote/voice-activity-detection") 
 1056-1060, 1124-1128).  Both return an `Annotation` whose `itertracks(yield_label=True)` yields
 (segment, track, label) with float `segment.start/.end` -- the only API the reference touches.
 
-The networks (SincNet/PyanNet segmentation, x-vector embedder) run in libccx; this module is the
-small host-side post-net (K22 in SURVEY.md): sliding windows, powerset decoding, overlap-add
+The networks (SincNet/PyanNet segmentation, WeSpeaker ResNet-34 embedder of speaker-diarization-3.1) run in libccx;
+this module is the small host-side post-net (K22 in SURVEY.md): sliding windows, powerset decoding, overlap-add
 aggregation, hysteresis binarisation, agglomerative clustering, timeline reconstruction, restated from
-recollection of pyannote.audio 3.x [UPSTREAM-RECALL].  Deviations (also in DESIGN.md): the diarization
-pipeline embeds local speakers with the x-vector network instead of the bundled
-wespeaker ResNet-34 (not built yet), and hyper-parameters are the recalled values of the published
-pipeline configs, overridable through the constructors.
+recollection of pyannote.audio 3.x [UPSTREAM-RECALL].  Hyper-parameters come from the pipelines' own config.yaml when it is
+on disk (weights.find_pipeline_config, wired in models.load_models); the constructor defaults are the recalled values of the
+published configs.
 """
 from __future__ import annotations
 
