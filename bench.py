@@ -120,6 +120,7 @@ def spawn_ranks(n: int) -> int:
 
 
 def main():
+    os.environ.setdefault("CCX_PROF_SHAPES", "1")      # per-shape GEMM labels in the profiled step (folded back below)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -334,8 +335,22 @@ def main():
                         frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic, launches=cnt_,
                         avg_launch_us=round(ms * 1e3 / cnt_, 2), bytes_per_launch=by / cnt_, measured=where)
 
+        # GEMM launches carry per-shape labels ("gemm<epi1,256x256> M=288000 N=3072 K=768 taps=1"): the encoder's are the ones whose
+        # M is the group's windows x 1500 / 1501 / 3000 rows (layers, conv2, conv1); all of them fold back into the family entry
+        nwin = min(args.whisper_group, 6 * B) if pipeline else B
+        enc_rows = {f" M={nwin * r} " for r in (1500, 1501, 3000)}
+        enc_fl = enc_ms = 0.0
+        enc_n = 0
+        folded = []
+        for name, fl, by, ms in recs:
+            if name.startswith("gemm<"):
+                if any(t in name for t in enc_rows):
+                    enc_fl += fl; enc_ms += ms; enc_n += 1
+                name = "gemm_bf16_nt_kernel"
+            folded.append((name, fl, by, ms))
+        recs = folded
         agg = aggregate_records(recs)
-        pagg = aggregate_records(probe)
+        pagg = aggregate_records([("gemm_bf16_nt_kernel" if n.startswith("gemm<") else n, f, b_, m) for n, f, b_, m in probe])
         # per-step totals: eager kernels as recorded over the timed steps; graph-resident decode kernels = probe average
         # launch time x their launches per step
         where_eager = "HIP events on the launch stream, one extra step of the same batch right after the timed region"
@@ -354,6 +369,11 @@ def main():
         if "gemm_bf16_nt_kernel" in agg and (roof is None or roof["kernel"] != "gemm_bf16_nt_kernel"):
             cnt_, fl, by, ms = agg["gemm_bf16_nt_kernel"]
             roof_mfma = roof_entry("gemm_bf16_nt_kernel", cnt_, fl, by, ms, where_eager)
+            roof_mfma["scope"] = "every GEMM launch of a step (encoder, ResNet-34, SepFormer, TDNN, heads, logits)"
+            if enc_ms > 0:
+                ach = enc_fl / (enc_ms * 1e-3) / 1e12
+                roof_mfma["whisper_encoder_gemms"] = dict(achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
+                                                          launches=enc_n, ms_per_step=round(enc_ms / prof_steps, 2))
         stage_ms = {k: round(v[3] / prof_steps, 3) for k, v in agg.items()}
         stage_ms.update({k: round(v[0], 3) for k, v in per_step.items()})
 

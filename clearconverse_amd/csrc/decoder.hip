@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restric
 int ccx_launch_dec_combine(ccx_ctx* ctx, const float* part_o, const float* part_ml, int nsplit, bf16_t* out, int M, int H,
                            hipStream_t stream) {
   CCX_REQUIRE(ctx, nsplit >= 1 && nsplit <= 8, "dec_combine: nsplit out of range");
+  ccx_prof_scope ps(ctx, stream, "dec_combine_kernel", 0.0, (double)M * H * nsplit * 66.0 * 4 + (double)M * H * 64 * 2);
   hipLaunchKernelGGL(dec_combine_kernel, dim3(ccx_cdiv(M * H * 8, 256)), dim3(256), 0, stream, part_o, part_ml, nsplit, out, M, H);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
@@ -446,6 +447,8 @@ int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, i
                               const float* b, bf16_t* out, float* x_out, int M, int K, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, K % 4 == 0 && K <= 1024, "dec_resolve_ln: K=%d unsupported", K);
   CCX_REQUIRE(ctx, x_out != x, "dec_resolve_ln: x_out must not alias x");
+  // bytes: the residual rows and their pending slabs in, the bf16 rows (and the resolved fp32 rows) out
+  ccx_prof_scope ps(ctx, stream, "dec_resolve_ln_kernel", 0.0, (double)M * K * (4.0 * (1 + pend_n) + 2.0 + (x_out ? 4.0 : 0.0)));
   hipLaunchKernelGGL(dec_resolve_ln_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, pend, pend_n, pend_stride, g, b,
                      out, x_out, M, K, eps);
   CCX_CHECK_LAUNCH(ctx);
@@ -817,7 +820,9 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
   CCX_REQUIRE(ctx, !final_out || nsplit == 1, "dec_attention: final output needs nsplit == 1");
   dim3 grid(B * p.H, nsplit);
   {
-    const double keys = p.pos ? 0.0 : (double)p.T;  // self-attention length varies per row: not priced
+    // self-attention length varies per row and is known on the device only: priced at one key (q in, one K/V row, out), so that
+    // the launch shows up in the per-kernel times without claiming traffic it may not have moved
+    const double keys = p.pos ? 1.0 : (double)p.T;
     // the cross attention keeps its profile label whatever variant runs (self attention: <true> with pos)
     ccx_prof_scope ps(ctx, stream, p.pos ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
                       (double)B * p.H * keys * 64 * 2 * 2);
@@ -1123,6 +1128,7 @@ int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_em
 }
 
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream) {
+  ccx_prof_scope ps(ctx, stream, "dec_select_kernel", 0.0, (double)B * p.n_vocab * 5.0);     // the logit row + its suppress mask
   if (p.sample) hipLaunchKernelGGL(dec_select_kernel<true>, dim3(B), dim3(1024), 0, stream, p);
   else hipLaunchKernelGGL(dec_select_kernel<false>, dim3(B), dim3(1024), 0, stream, p);
   CCX_CHECK_LAUNCH(ctx);
