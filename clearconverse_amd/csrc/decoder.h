@@ -18,8 +18,9 @@ struct DecLinearParams {
   const float* part_o; const float* part_ml; int nsplit;  // ACT_COMBINE: [M][H][nsplit][64], [M][H][nsplit][2]
   // outputs (DEPI_PARTIAL: out[z][m][n] with stride pend_stride between the grid.z slices)
   void* out; long ldo;
-  // DEPI_SELF_QKV: q -> out (f32 [M][K]), k/v -> caches [M][H][cache_T][64] at pos[m]
-  bf16_t* cache_k; bf16_t* cache_v; int cache_T; const int* pos;
+  // DEPI_SELF_QKV: q -> out (f32 [M][K]), k/v -> caches [sequence][H][cache_T][64] at pos[m]; the sequence of row m is
+  // row_seq[m] (prompt prefill: several rows per sequence) or m itself when row_seq is null
+  bf16_t* cache_k; bf16_t* cache_v; int cache_T; const int* pos; const int* row_seq;
 };
 int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams& p, hipStream_t stream);
 // number of grid.z K-slices ccx_launch_dec_linear will use (= number of partial slabs written)
@@ -41,6 +42,9 @@ struct DecAttnParams {
   float* part_ml;       // [B][H][nsplit][2]
   int lds_pad;          // dynamic LDS the blocks claim without using it: caps the blocks per CU (see ccx_whisper_decode)
   int stream_mode;      // cross attention only: 1 = dec_cross_stream_kernel (few waves, few bytes in flight per CU)
+  // prompt prefill: rows (q / out index) != sequences (K/V index).  row_seq [rows] maps them (null: identity); rows_per_seq > 1
+  // tells the cross attention that the rows of a sequence are consecutive, so that it can co-schedule them on one XCD
+  const int* row_seq; int rows_per_seq;
 };
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out, hipStream_t stream);
 
@@ -70,5 +74,7 @@ struct DecSelectParams {
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,
                          float* x, int B, int D, hipStream_t stream);
+// dst[i][:] = src[idx[i]][:] (bf16 rows of D elements): the last prompt row of every sequence after a prefill
+int ccx_launch_dec_gather_rows(ccx_ctx* ctx, const bf16_t* src, const int* idx, bf16_t* dst, int n, int D, hipStream_t stream);
 int ccx_launch_dec_combine(ccx_ctx* ctx, const float* part_o, const float* part_ml, int nsplit, bf16_t* out, int M, int H,
                            hipStream_t stream);

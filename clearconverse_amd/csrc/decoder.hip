@@ -330,10 +330,11 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         const int hh = nn >> 6, d = nn & 63;
         const int H = D >> 6;
         bf16_t* cache = which ? p.cache_v : p.cache_k;
+        const int sq = p.row_seq ? p.row_seq[m] : m;
         uint2 pk;
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
-        *(uint2*)(cache + (((long)m * H + hh) * p.cache_T + pos_v[it]) * 64 + d) = pk;
+        *(uint2*)(cache + (((long)sq * H + hh) * p.cache_T + pos_v[it]) * 64 + d) = pk;
       }
     }
   }
@@ -432,6 +433,19 @@ __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restric
   pk.x = pack_bf16x2(o[0] * inv, o[1] * inv); pk.y = pack_bf16x2(o[2] * inv, o[3] * inv);
   pk.z = pack_bf16x2(o[4] * inv, o[5] * inv); pk.w = pack_bf16x2(o[6] * inv, o[7] * inv);
   *(uint4*)(out + ((long)m * H + h) * 64 + 8 * c) = pk;
+}
+
+__global__ void dec_gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst, int D) {
+  const uint4* s4 = (const uint4*)(src + (long)idx[blockIdx.x] * D);
+  uint4* d4 = (uint4*)(dst + (long)blockIdx.x * D);
+  for (int i = threadIdx.x; i < D / 8; i += blockDim.x) d4[i] = s4[i];
+}
+
+int ccx_launch_dec_gather_rows(ccx_ctx* ctx, const bf16_t* src, const int* idx, bf16_t* dst, int n, int D, hipStream_t stream) {
+  CCX_REQUIRE(ctx, src && idx && dst && n >= 1 && D % 8 == 0, "dec_gather_rows: bad arguments");
+  hipLaunchKernelGGL(dec_gather_rows_kernel, dim3(n), dim3(128), 0, stream, src, idx, dst, D);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
 }
 
 int ccx_launch_dec_combine(ccx_ctx* ctx, const float* part_o, const float* part_ml, int nsplit, bf16_t* out, int M, int H,
@@ -550,15 +564,16 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
   __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, split = blockIdx.y;
-  const int b = bh / p.H, h = bh - b * p.H;
+  const int b = bh / p.H, h = bh - b * p.H;        // b: row (q / out); its K/V belong to sequence sq
+  const int sq = p.row_seq ? p.row_seq[b] : b;
   const int g = lane >> 3, c = lane & 7;
   const int T = p.pos ? (p.pos[b] + 1) : p.T;
   const int per = (T + gridDim.y - 1) / gridDim.y;
   const int kbeg = split * per;
   const int kend = (kbeg + per < T) ? kbeg + per : T;
 
-  const bf16_t* Kb = p.k + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
-  const bf16_t* Vb = p.v + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Kb = p.k + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Vb = p.v + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
 
   float sm = -1e30f, sl = 0.f, so[8];
 #pragma unroll
@@ -669,12 +684,28 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
 // (two named register sets; hipcc leaves the younger 8 loads in flight: s_waitcnt vmcnt(8)).
 // NP = 32-key pieces per wave (compile-time: the loop is fully unrolled into straight-line code, because with a real loop
 // hipcc keeps the loop-carried piece in other registers than it loads into and copies it at the loop end behind a vmcnt(0)).
-template <bool FINAL, int NP>
+// PRE (prompt prefill): a sequence has rows_per_seq consecutive rows (one per prompt position) that all attend to ITS K/V.  Logical
+// block L = (sequence * H + head) * rows_per_seq + t, and the launch order is remapped (the GEMM's XCD-aware bijective map) so
+// that the rows of one (sequence, head) run on one XCD at about the same time: the first one brings the 384 KB of K/V into
+// that XCD's L2, the others hit it -- the prompt costs about one step of HBM traffic instead of one per prompt token.  Loads are
+// cacheable here (non-temporal for the decode steps, where every byte is used once).
+template <bool FINAL, int NP, bool PRE = false>
 __global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) {
   __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.x, split = blockIdx.y;
-  const int b = bh / p.H, h = bh - b * p.H;
+  const int split = blockIdx.y;
+  int b, h, sq;                                      // row (q / out), head, sequence (K/V)
+  if (PRE) {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int t = L % p.rows_per_seq, sh = L / p.rows_per_seq;
+    h = sh % p.H; sq = sh / p.H;
+    b = sq * p.rows_per_seq + t;
+  } else {
+    const int bh = blockIdx.x;
+    b = bh / p.H; h = bh - b * p.H; sq = b;
+  }
   const int g = lane >> 3, c = lane & 7;
   const int T = p.T;
   const int per = (T + gridDim.y - 1) / gridDim.y;
@@ -687,8 +718,8 @@ __global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) 
   const int w0 = __builtin_amdgcn_readfirstlane(kbeg + wave * per_w);
   const int w1 = __builtin_amdgcn_readfirstlane((w0 + per_w < kend) ? w0 + per_w : kend);
 
-  const bf16_t* Kb = p.k + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
-  const bf16_t* Vb = p.v + ((long)b * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Kb = p.k + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Vb = p.v + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
 
   float sm = -1e30f, sl = 0.f, so[8];
 #pragma unroll
@@ -708,9 +739,10 @@ __global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) 
       off[it] = (long)key * 64;
     }
 #pragma unroll
-    for (int it = 0; it < 4; it++) kf[it] = __builtin_nontemporal_load((const bf16x8*)(Kb + off[it]));   // K first: the scores need it first
+    for (int it = 0; it < 4; it++)   // K first: the scores need it first
+      kf[it] = PRE ? *(const bf16x8*)(Kb + off[it]) : __builtin_nontemporal_load((const bf16x8*)(Kb + off[it]));
 #pragma unroll
-    for (int it = 0; it < 4; it++) vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vb + off[it]));
+    for (int it = 0; it < 4; it++) vf[it] = PRE ? *(const bf16x8*)(Vb + off[it]) : __builtin_nontemporal_load((const bf16x8*)(Vb + off[it]));
   };
   auto reduce = [&](const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int base) {
     float s[4];
@@ -824,11 +856,19 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
     // the launch shows up in the per-kernel times without claiming traffic it may not have moved
     const double keys = p.pos ? 1.0 : (double)p.T;
     // the cross attention keeps its profile label whatever variant runs (self attention: <true> with pos)
-    ccx_prof_scope ps(ctx, stream, p.pos ? "dec_attention_kernel<true>" : "dec_attention_kernel<false>", 4.0 * B * p.H * keys * 64,
+    ccx_prof_scope ps(ctx, stream, p.pos ? "dec_attention_kernel<true>" : (p.rows_per_seq > 1 ? "dec_cross_prefill" : "dec_attention_kernel<false>"),
+                      4.0 * B * p.H * keys * 64 * (p.rows_per_seq > 1 && !p.pos ? p.rows_per_seq : 1),
                       (double)B * p.H * keys * 64 * 2 * 2);
     // pieces per wave: keys per block / 4 waves, rounded up to 32 (the kernel's own formula)
     const int np_need = p.pos ? 0 : ((ccx_cdiv(ccx_cdiv(p.T, nsplit), 4) + 31) / 32);
-    if (p.stream_mode && !p.pos && np_need <= 12) {
+    if (p.rows_per_seq > 1 && !p.pos) {
+      // prompt prefill: B = sequences here, one block per (sequence, head, prompt row), whole key range per block
+      CCX_REQUIRE(ctx, nsplit == 1 && final_out && np_need <= 12, "dec_attention: the prefill cross attention takes the whole key range (T <= 1536)");
+      dim3 pgrid(B * p.H * p.rows_per_seq, 1);
+      if (np_need <= 4) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 4, true>), pgrid, dim3(256), 0, stream, p);
+      else if (np_need <= 6) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 6, true>), pgrid, dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((dec_cross_stream_kernel<true, 12, true>), pgrid, dim3(256), 0, stream, p);
+    } else if (p.stream_mode && !p.pos && np_need <= 12) {
       const int pad = p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0;
 #define CCX_CROSS_STREAM_LAUNCH(F, ...)                                                                                      \
   do {                                                                                                                       \

@@ -108,6 +108,12 @@ struct ccx_whisper {
   unsigned* sample_cfg = nullptr;   // {temperature bits, seed lo, seed hi, 0}: read by the select kernel every step
   DecSeqState* state = nullptr;
   int max_prompt_cap = 0, sample_cap = 0;
+  // prompt prefill: one pass over every prompt position of every sequence (rows = sequence * P + position) instead of one
+  // decode step per prompt token; row-indexed copies of the step buffers and the row tables
+  static constexpr int kPrefillMax = 16;     // longest prompt (tokens) prefilled in one pass; longer ones are fed step by step
+  float *pf_x = nullptr, *pf_x2 = nullptr, *pf_pend = nullptr, *pf_q = nullptr;
+  bf16_t *pf_xn = nullptr, *pf_attn = nullptr, *pf_ffn = nullptr;
+  int *pf_tok = nullptr, *pf_pos = nullptr, *pf_seq = nullptr, *pf_last = nullptr;
   // graph cache; decode runs on an internal stream when the caller hands over the legacy null
   // stream (stream capture is illegal there)
   std::map<std::array<int, 9>, hipGraphExec_t> graphs;
@@ -515,6 +521,14 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   TRY(dev_alloc(w, &w->n_done, (size_t)4, true));
   TRY(dev_alloc(w, &w->sample_cfg, (size_t)4, true));
   TRY(dev_alloc(w, &w->state, (size_t)B, true));
+  {
+    const size_t R = (size_t)B * ccx_whisper::kPrefillMax;
+    TRY(dev_alloc(w, &w->pf_x, R * D, true)); TRY(dev_alloc(w, &w->pf_x2, R * D, true)); TRY(dev_alloc(w, &w->pf_pend, 4 * R * D, true));
+    TRY(dev_alloc(w, &w->pf_q, R * D, true)); TRY(dev_alloc(w, &w->pf_xn, R * D, true)); TRY(dev_alloc(w, &w->pf_attn, R * D, true));
+    TRY(dev_alloc(w, &w->pf_ffn, R * F, true));
+    TRY(dev_alloc(w, &w->pf_tok, R, true)); TRY(dev_alloc(w, &w->pf_pos, R, true)); TRY(dev_alloc(w, &w->pf_seq, R, true));
+    TRY(dev_alloc(w, &w->pf_last, (size_t)B, true));
+  }
   w->max_prompt_cap = d.n_text_ctx;
   w->sample_cap = d.n_text_ctx;
   TRY(dev_alloc(w, &w->prompt, (size_t)B * w->max_prompt_cap, true));
@@ -737,30 +751,80 @@ int cross_split(int B, int H, bool capped, bool lean = false) {
   return ns;
 }
 
+// Tail of a step for the sequences [b0, b0 + B): logits of the final-LayerNorm rows (w->dxn) against the tied embedding, then
+// the select kernel (filters, argmax / sampling, state machine, next step's embedding).
+int dec_head(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, int* n_done,
+             hipStream_t stream) {
+  ccx_ctx* ctx = w->ctx;
+  const ccx_whisper_dims& d = w->d;
+  const int D = d.n_text_state;
+  const long ro = b0;
+  bf16_t* dxn = w->dxn + ro * D;
+  int* pos = w->pos + b0;
+  {
+    // logits against the tied embedding through the tiled GEMM (one summation order for every batch size; 284 -> 282 ms
+    // for 192 sequences x 65 steps, no change at 8 sequences); CCX_LOGITS_GEMM=0 selects the skinny kernel
+    static const int gemm_logits = [] { const char* e = getenv("CCX_LOGITS_GEMM"); return e ? atoi(e) : 1; }();
+    if (gemm_logits && D % 64 == 0) {
+      GemmParams gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = dxn; gp.lda = D; gp.W = w->tok_emb_rm; gp.ldw = D; gp.M = B; gp.N = d.n_vocab; gp.K = D; gp.out = logits; gp.ldo = ld;
+      TRY(ccx_launch_gemm(ctx, EPI_F32, gp, stream));
+    } else {
+      DecLinearParams lp;
+      memset(&lp, 0, sizeof(lp));
+      lp.M = B; lp.N = d.n_vocab; lp.K = D; lp.W = w->tok_emb_bf16; lp.ldw = D; lp.bias = nullptr;
+      lp.act = dxn; lp.lda = D; lp.out = logits; lp.ldo = ld;
+      TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32, lp, stream));
+    }
+  }
+  if (select) {
+    DecSelectParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.logits = logits; sp.ld_logits = ld; sp.n_vocab = d.n_vocab; sp.state = w->state + b0; sp.prompt = w->prompt + ro * max_prompt;
+    sp.max_prompt = max_prompt; sp.cur_tok = w->cur_tok + b0; sp.pos = pos; sp.gen = w->gen + ro * sample_len; sp.sample_len = sample_len;
+    sp.n_done = n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
+    sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
+    sp.max_initial_ts = w->rules.max_initial_timestamp_index;
+    sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx + ro * D; sp.D = D;
+    sp.sample_cfg = w->sample_cfg; sp.row0 = b0; sp.sample = w->sampling ? 1 : 0;
+    TRY(ccx_launch_dec_select(ctx, sp, B, stream));
+  }
+  return CCX_OK;
+}
+
 // One decoder step for the B sequences [b0, b0 + B) on `stream` (a "lane": every per-sequence buffer is
 // addressed through its row offset, so disjoint lanes can step concurrently on different streams).
 // logits go to `logits` (row 0 = sequence b0) with row stride ld.  The residual stream ping-pongs between
 // dx and dx2: out-proj / cross-out / FFN2 only write split-K partial slabs (pend) and the next LayerNorm
 // folds them in (decoder.hip).  `stagger`, if set, is recorded right before layer 0's cross attention.
+// `prefill_rows` = P > 0: the PROMPT PREFILL pass instead of a step -- B sequences x P prompt positions as B * P rows of the pf_*
+// buffers (row = sequence * P + position), self-KV written at every position, cross attention with all rows of a sequence
+// sharing its K/V, no logits / select (the caller takes the last prompt row of every sequence).
 int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select, int sample_len, int max_prompt, int* n_done,
-             hipStream_t stream, hipEvent_t stagger = nullptr, int lane_idx = 0) {
+             hipStream_t stream, hipEvent_t stagger = nullptr, int lane_idx = 0, int prefill_rows = 0) {
   ccx_ctx* ctx = w->ctx;
   const ccx_whisper_dims& d = w->d;
   const int D = d.n_text_state, F = 4 * D, H = d.n_text_head, Tc = d.n_text_ctx;
   const float scale_log2e = 0.125f * 1.4426950408889634f;
   const int ns = cross_split(B, H, w->cross_lds_pad > 0, w->cross_stream != 0);
-  const long pstride = (long)B * D;
+  long pstride = (long)B * D;
   const long ro = b0;
-  float* cur = w->dx + ro * D;     // stream (minus the pending partials); the step's embedding is in dx
-  float* other = w->dx2 + ro * D;
-  float* pend = w->pend + 4 * ro * D;
-  float* dq = w->dq + ro * D;
-  bf16_t* dxn = w->dxn + ro * D;
-  bf16_t* dattn = w->dattn + ro * D;
-  bf16_t* dffn = w->dffn + ro * F;
+  const bool pre = prefill_rows > 0;
+  const int nseq = B;                                  // sequences of this call
+  if (pre) B = nseq * prefill_rows;                    // rows the chain works on
+  pstride = (long)B * D;
+  float* cur = pre ? w->pf_x : w->dx + ro * D;     // stream (minus the pending partials); the step's embedding is in dx
+  float* other = pre ? w->pf_x2 : w->dx2 + ro * D;
+  float* pend = pre ? w->pf_pend : w->pend + 4 * ro * D;
+  float* dq = pre ? w->pf_q : w->dq + ro * D;
+  bf16_t* dxn = pre ? w->pf_xn : w->dxn + ro * D;
+  bf16_t* dattn = pre ? w->pf_attn : w->dattn + ro * D;
+  bf16_t* dffn = pre ? w->pf_ffn : w->dffn + ro * F;
   float* part_o = w->part_o + ro * H * ccx_whisper::kCrossSplitMax * 64;
   float* part_ml = w->part_ml + ro * H * ccx_whisper::kCrossSplitMax * 2;
-  int* pos = w->pos + b0;
+  int* pos = pre ? w->pf_pos : w->pos + b0;
+  const int* row_seq = pre ? w->pf_seq : nullptr;
   const long cross_off = ro * H * w->Spad * 64, self_off = ro * H * Tc * 64;
   static const int stamp_level = [] { const char* e = getenv("CCX_DEC_STAMP_LEVEL"); return e ? atoi(e) : 1; }();
   auto stamp = [&](int tag, int level) {
@@ -818,14 +882,14 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     {
       DecLinearParams ex;
       memset(&ex, 0, sizeof(ex));
-      ex.cache_k = L.selfK + self_off; ex.cache_v = L.selfV + self_off; ex.cache_T = Tc; ex.pos = pos;
+      ex.cache_k = L.selfK + self_off; ex.cache_v = L.selfV + self_off; ex.cache_T = Tc; ex.pos = pos; ex.row_seq = row_seq;
       TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, dq, D, &ex));
       stamp(16, 2);
     }
     DecAttnParams ap;
     memset(&ap, 0, sizeof(ap));
     ap.q = dq; ap.k = L.selfK + self_off; ap.v = L.selfV + self_off; ap.H = H; ap.kv_T = Tc; ap.pos = pos; ap.scale_log2e = scale_log2e;
-    ap.out_bf16 = dattn;
+    ap.out_bf16 = dattn; ap.row_seq = row_seq;
     TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
     stamp(17, 2);
     TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
@@ -839,7 +903,16 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
     ap.lds_pad = w->cross_lds_pad;
     ap.stream_mode = (w->cross_stream && B > 16) ? 1 : 0;
-    if (ablate == 1 && B > 16) {
+    if (pre) {
+      ap.row_seq = row_seq; ap.rows_per_seq = prefill_rows; ap.lds_pad = 0; ap.stream_mode = 1;
+      if (prefill_rows > 1) {
+        TRY(ccx_launch_dec_attention(ctx, ap, nseq, 1, true, stream));
+      } else {
+        ap.row_seq = nullptr; ap.rows_per_seq = 0;
+        TRY(ccx_launch_dec_attention(ctx, ap, nseq, 1, true, stream));
+      }
+      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+    } else if (ablate == 1 && B > 16) {
       TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
     } else if (B > 16) {
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, ns == 1, stream));
@@ -859,41 +932,16 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   }
   // resolve the last partials + final LN, then logits against the tied embedding
   TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, w->lnd_g, w->lnd_b, dxn, nullptr, B, D, 1e-5f, stream));
-  {
-    // logits against the tied embedding through the tiled GEMM (one summation order for every batch size; 284 -> 282 ms
-    // for 192 sequences x 65 steps, no change at 8 sequences); CCX_LOGITS_GEMM=0 selects the skinny kernel
-    static const int gemm_logits = [] { const char* e = getenv("CCX_LOGITS_GEMM"); return e ? atoi(e) : 1; }();
-    if (gemm_logits && D % 64 == 0) {
-      GemmParams gp;
-      memset(&gp, 0, sizeof(gp));
-      gp.A = dxn; gp.lda = D; gp.W = w->tok_emb_rm; gp.ldw = D; gp.M = B; gp.N = d.n_vocab; gp.K = D; gp.out = logits; gp.ldo = ld;
-      TRY(ccx_launch_gemm(ctx, EPI_F32, gp, stream));
-    } else {
-      DecLinearParams lp;
-      memset(&lp, 0, sizeof(lp));
-      lp.M = B; lp.N = d.n_vocab; lp.K = D; lp.W = w->tok_emb_bf16; lp.ldw = D; lp.bias = nullptr;
-      lp.act = dxn; lp.lda = D; lp.out = logits; lp.ldo = ld;
-      TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_F32, lp, stream));
-    }
-  }
-  if (select) {
-    DecSelectParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.logits = logits; sp.ld_logits = ld; sp.n_vocab = d.n_vocab; sp.state = w->state + b0; sp.prompt = w->prompt + ro * max_prompt;
-    sp.max_prompt = max_prompt; sp.cur_tok = w->cur_tok + b0; sp.pos = pos; sp.gen = w->gen + ro * sample_len; sp.sample_len = sample_len;
-    sp.n_done = n_done; sp.suppress_mask = w->suppress_mask; sp.eot = w->rules.eot; sp.blank = w->rules.blank;
-    sp.no_speech = w->rules.no_speech; sp.timestamp_begin = w->rules.timestamp_begin;
-    sp.max_initial_ts = w->rules.max_initial_timestamp_index;
-    sp.tok_emb = w->tok_emb_f32; sp.pos_emb = w->dec_pos; sp.x = w->dx + ro * D; sp.D = D;
-    sp.sample_cfg = w->sample_cfg; sp.row0 = b0; sp.sample = w->sampling ? 1 : 0;
-    TRY(ccx_launch_dec_select(ctx, sp, B, stream));
-  }
+  if (pre) return CCX_OK;         // the caller gathers the last prompt row of every sequence out of pf_xn
+  TRY(dec_head(w, b0, B, logits, ld, select, sample_len, max_prompt, n_done, stream));
   stamp(3, 1);       // end of the step
   return CCX_OK;
 }
 
+// `prefilled`: the prompts go through the prefill pass, so every sequence starts at its LAST prompt position (the state machine's
+// sampling phase) and the first embedding comes from the prefill, not from here.
 int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B,
-                        float temperature, uint64_t seed, hipStream_t stream) {
+                        float temperature, uint64_t seed, hipStream_t stream, bool prefilled = false) {
   std::vector<DecSeqState> st(B);
   std::vector<int> tok(B), ps(B, 0);
   for (int b = 0; b < B; b++) {
@@ -901,6 +949,11 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
     st[b].prompt_len = prompt_lens[b];
     st[b].last_tok = -1; st[b].pen_tok = -1; st[b].last_ts_tok = -1;
     tok[b] = prompt_ids[(size_t)b * max_prompt];
+    if (prefilled) {
+      st[b].pos = prompt_lens[b] - 1;
+      ps[b] = prompt_lens[b] - 1;
+      tok[b] = prompt_ids[(size_t)b * max_prompt + prompt_lens[b] - 1];
+    }
   }
   CCX_HIP(w->ctx, hipMemcpyAsync(w->state, st.data(), B * sizeof(DecSeqState), hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->cur_tok, tok.data(), B * 4, hipMemcpyHostToDevice, stream));
@@ -912,9 +965,36 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
   memcpy(&cfg[0], &temperature, 4);
   CCX_HIP(w->ctx, hipMemcpyAsync(w->sample_cfg, cfg, sizeof(cfg), hipMemcpyHostToDevice, stream));
   // embedding of the first token; later steps get theirs from the select kernel
-  TRY(ccx_launch_dec_embed(w->ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, w->d.n_text_state, stream));
+  if (!prefilled) TRY(ccx_launch_dec_embed(w->ctx, w->tok_emb_f32, w->dec_pos, w->cur_tok, w->pos, w->dx, B, w->d.n_text_state, stream));
   CCX_HIP(w->ctx, hipStreamSynchronize(stream));  // host vectors go out of scope
   return CCX_OK;
+}
+
+// Prompt prefill (openai-whisper's first forward over all initial tokens, decoding.py::_main_loop): every prompt position of every
+// sequence in ONE pass of the layer chain -- P = longest prompt, rows = sequence * P + position, positions past a shorter prompt
+// are dead rows (their K/V land beyond the prompt and are overwritten by the tokens decoded there later).  Leaves the self-KV
+// caches filled and the final-LayerNorm row of every sequence's last prompt position in w->dxn.
+int run_prefill(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B, int P, int sample_len,
+                hipStream_t stream) {
+  ccx_ctx* ctx = w->ctx;
+  const int R = B * P, D = w->d.n_text_state;
+  std::vector<int> tok(R), ps(R), sq(R), last(B);
+  for (int b = 0; b < B; b++) {
+    for (int t = 0; t < P; t++) {
+      const int r = b * P + t;
+      tok[r] = t < prompt_lens[b] ? prompt_ids[(size_t)b * max_prompt + t] : w->rules.eot;
+      ps[r] = t; sq[r] = b;
+    }
+    last[b] = b * P + prompt_lens[b] - 1;
+  }
+  CCX_HIP(ctx, hipMemcpyAsync(w->pf_tok, tok.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(ctx, hipMemcpyAsync(w->pf_pos, ps.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(ctx, hipMemcpyAsync(w->pf_seq, sq.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+  CCX_HIP(ctx, hipMemcpyAsync(w->pf_last, last.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
+  TRY(ccx_launch_dec_embed(ctx, w->tok_emb_f32, w->dec_pos, w->pf_tok, w->pf_pos, w->pf_x, R, D, stream));
+  CCX_HIP(ctx, hipStreamSynchronize(stream));     // host tables go out of scope
+  TRY(dec_step(w, 0, B, nullptr, 0, false, sample_len, max_prompt, nullptr, stream, nullptr, 0, P));
+  return ccx_launch_dec_gather_rows(ctx, w->pf_xn, w->pf_last, w->dxn, B, D, stream);
 }
 
 }  // namespace
@@ -988,8 +1068,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     }
     if (prompt_lens[b] > max_pl) max_pl = prompt_lens[b];
   }
-  TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, temperature, seed, stream));
-  const int total_steps = max_pl - 1 + sample_len;
+  // prompts of 2 .. kPrefillMax tokens are prefilled in one pass (CCX_PREFILL=0: one decode step per prompt token, round 1's way)
+  const int prefill_on = [] { const char* e = getenv("CCX_PREFILL"); return e ? atoi(e) : 1; }();     // read per call: tests flip it
+  const bool prefill = prefill_on && max_pl >= 2 && max_pl <= ccx_whisper::kPrefillMax;
+  TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, temperature, seed, stream, prefill));
+  // steps still to run after the (eager) first one: the prefill already covers the prompt AND takes the first sample below
+  const int total_steps = prefill ? sample_len : max_pl - 1 + sample_len;
   const bool use_graph = getenv("CCX_NO_GRAPH") == nullptr;
   const long ld = w->Vpad;
 
@@ -1032,7 +1116,13 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     }
     nl = n;
   }
-  // the state upload was queued on `stream`: the other lanes start after it
+  if (prefill) {
+    TRY(run_prefill(w, prompt_ids, prompt_lens, max_prompt, B, max_pl, sample_len, stream));
+    // first sample of every sequence, lane by lane (each lane counts its own finished sequences)
+    for (int i = 0; i < nl; i++)
+      TRY(dec_head(w, lanes[i].b0, lanes[i].B, w->dlogits + (long)lanes[i].b0 * ld, ld, true, sample_len, max_prompt, w->n_done + i, stream));
+  }
+  // the state upload (and the prefill) was queued on `stream`: the other lanes start after it
   CCX_HIP(ctx, hipEventRecord(w->own_event, stream));
   for (int i = 1; i < nl; i++) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->own_event, 0));
   auto step_lane = [&](int i, hipEvent_t stagger) -> int {
@@ -1041,13 +1131,16 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   };
   // first step runs eagerly (also performs one-time kernel attribute setup outside of capture).  Lane i + 1
   // starts when lane i reaches its first cross attention, which sets the stagger the later steps keep.
-  for (int i = 0; i < nl; i++) {
-    if (i > 0) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
-    TRY(step_lane(i, (i + 1 < nl) ? w->lane_start[i] : nullptr));
-    if (ctx->prof_on && !use_graph && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+  int step = prefill ? 1 : 0;                   // the prefill's own sample counts as step 0
+  if (step < total_steps) {
+    for (int i = 0; i < nl; i++) {
+      if (i > 0) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
+      TRY(step_lane(i, (i + 1 < nl) ? w->lane_start[i] : nullptr));
+      if (ctx->prof_on && !use_graph && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
+    }
+    step += 1;
   }
-  int step = 1;
-  if (use_graph && total_steps > 1) {
+  if (use_graph && step < total_steps) {
     for (int i = 0; i < nl; i++) {
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count

@@ -354,3 +354,46 @@ def test_long_audio_multi_window_logmel_and_transcribe(ccx_ctx):
             m.transcribe(np.zeros(16000 * 90, dtype=np.float32))          # beyond max_audio_seconds: loud failure
     finally:
         m.close()
+
+
+def test_prompt_prefill_equals_stepwise_prompt_feeding(ccx_ctx, monkeypatch):
+    """Prompts of 2..16 tokens are prefilled in ONE pass over all prompt positions (rows = sequence x position, the rows of a
+    sequence sharing its cross K/V; openai-whisper's first forward) instead of one decode step per prompt token (CCX_PREFILL=0).
+    Same kernels per row, so the sampled tokens must agree -- ragged prompt lengths (2, 9, 5, 16 tokens; a 1-token prompt keeps the
+    stepwise path), small batch and a 40-sequence batch in lanes, greedy and sampled.  Both are checked against the oracle too."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        g = np.random.default_rng(5)
+        prompts = [[rules.sot_prev, 1000, rules.sot],
+                   [rules.sot_prev] + [int(x) for x in g.integers(1000, 40000, 7)] + [rules.sot],
+                   [rules.sot_prev, 300, 400, 500, rules.sot],
+                   [rules.sot_prev] + [int(x) for x in g.integers(1000, 40000, 14)] + [rules.sot]]
+        m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
+        a = m.decode_greedy(prompts, sample_len=10)
+        monkeypatch.setenv("CCX_PREFILL", "0")
+        b = m.decode_greedy(prompts, sample_len=10)
+        monkeypatch.delenv("CCX_PREFILL")
+        for i in range(4):
+            assert a[i]["tokens"] == b[i]["tokens"], (i, a[i]["tokens"], b[i]["tokens"])
+            assert abs(a[i]["sum_logprob"] - b[i]["sum_logprob"]) < 2e-3 * max(1.0, abs(b[i]["sum_logprob"]))
+            assert abs(a[i]["no_speech_prob"] - b[i]["no_speech_prob"]) < 1e-5
+        _check_greedy(dims, sd, m, xa, prompts, sample_len=10, tol=0.08)            # the prefilled path against the oracle
+        s1 = m.decode(prompts, sample_len=8, temperature=0.7, seed=11)
+        monkeypatch.setenv("CCX_PREFILL", "0")
+        s0 = m.decode(prompts, sample_len=8, temperature=0.7, seed=11)
+        monkeypatch.delenv("CCX_PREFILL")
+        assert [r["tokens"] for r in s1] == [r["tokens"] for r in s0]
+        big = dev.repeat(10, 1).contiguous()
+        m.log_mel(big, n * 10); m.encode(40)
+        c = m.decode_greedy(prompts * 10, sample_len=10)                          # 40 x 16 = 640 prefill rows, then lanes
+        for i in range(40):
+            assert c[i]["tokens"] == a[i % 4]["tokens"], i
+        one = m.decode_greedy([prompts[1]], sample_len=1)                         # sample_len 1: the prefill's own sample is the only one
+        assert one[0]["tokens"] == a[1]["tokens"][:1]
+    finally:
+        m.close()
