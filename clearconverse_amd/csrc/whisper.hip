@@ -1100,8 +1100,9 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     static const int forced_pad = [] { const char* e = getenv("CCX_CROSS_LDS_PAD"); return e ? atoi(e) : -1; }();
     static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 1; }();
     w->cross_stream = lean;
-    // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight
-    w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (lean ? 98304 : (nl > 1 ? 65536 : 0));
+    // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight.  The claim only exists to
+    // leave room for the OTHER lanes' chain kernels: a single lane runs uncapped.
+    w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? (lean ? 98304 : 65536) : 0);
   }
   struct Lane { int b0, B; hipStream_t s; hipGraphExec_t exec; };
   Lane lanes[ccx_whisper::kMaxLanes];
