@@ -128,19 +128,10 @@ __device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& vali
   return (long)g * p.rpb_out + i + p.roff;
 }
 
-template <int EPI, int WM, int WN, int MT>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT == 4 ? 2 : 1) : 4) void gemm_bf16_nt_kernel(GemmParams p) {
-  constexpr int TBM = WM * MT * 16, TBN = WN * 64;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (p.N + TBN - 1) / TBN;
-  // XCD-aware bijective remap (blocks b, b+8 share an XCD/L2): give each XCD a contiguous
-  // run of tiles so the A row-panel and the (small) W are re-read from that XCD's L2.
-  const int nwg = gridDim.x, orig = blockIdx.x;
-  const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
-  const int m0 = tm * TBM, n0 = tn * TBN;
-
+// Epilogue of one output tile: `acc` as left by a SWAP main loop (lane: one output row, 16 consecutive columns), or by the
+// un-swapped one for V^T destinations.  MAINLOOP is a functor (p, smem, m0, n0, acc, swap_tag).
+template <int EPI, int WM, int WN, int MT, typename MainLoop>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, MainLoop mainloop) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int l15 = lane & 15, h = lane >> 4;
@@ -154,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
   if (EPI == EPI_HEADS) {
     const int blk = n0 / p.d_model + p.first_block;  // 0=q 1=k 2=v  (d_model % 128 == 0)
     if (blk == 2 && p.v_transposed) {
-      gemm_mainloop<false, WM, WN, MT>(p, smem, m0, n0, acc);
+      mainloop(p, smem, m0, n0, acc, std::false_type{});
       // lane: column n = n0 + wc*64 + 16q + 4j + u ; rows m0 + wr*64 + mt*16 + 4h + reg
       const int q = l15 >> 2, u = l15 & 3;
 #pragma unroll
@@ -179,7 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
     }
   }
 
-  gemm_mainloop<true, WM, WN, MT>(p, smem, m0, n0, acc);
+  mainloop(p, smem, m0, n0, acc, std::true_type{});
 
   // lane: row m = m0 + wr*64 + mt*16 + l15 ; columns nb .. nb+15, value index 4j+reg
   const int nb = n0 + wc * 64 + 16 * h;
@@ -188,139 +179,352 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
 #pragma unroll
   for (int i = 0; i < 16; i++) bias[i] = 0.f;
   if (p.bias) {
+    if (nb + 16 <= p.N && ((uintptr_t)p.bias & 15) == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) bias[i] = (nb + i < p.N) ? p.bias[nb + i] : 0.f;
+      for (int i = 0; i < 4; i++) {
+        const float4 b4 = ((const float4*)(p.bias + nb))[i];
+        bias[4 * i] = b4.x; bias[4 * i + 1] = b4.y; bias[4 * i + 2] = b4.z; bias[4 * i + 3] = b4.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i++) bias[i] = (nb + i < p.N) ? p.bias[nb + i] : 0.f;
+    }
   }
+  // Consume the bias HERE, in straight-line code: hipcc otherwise waits for it with a `vmcnt(0)` at the head of every row
+  // tile's block (it cannot prove across the branches that the loads have been waited for), and since stores count in vmcnt
+  // each row tile then waited for the previous one's stores to land -- eight dependent store round trips per output tile.
+#pragma unroll
+  for (int i = 0; i < 16; i++) asm volatile("" ::"v"(bias[i]));
 
-  // Rows are finished in groups of GM row tiles: the residual rows of the whole group are requested before the first of
-  // them is needed (one memory round trip per group instead of one per row tile: the fp32-residual epilogue of a 256 x 256
-  // tile used to be eight dependent load -> add -> store rounds).
-  constexpr int GM = 4;
+  // Rows are finished in groups of GM row tiles, software-pipelined: the residual rows of group g+1 are requested BEFORE group
+  // g is finished and stored.  Stores count in vmcnt like loads and retire in order, so a residual load issued after a store
+  // can only be waited for together with that store; requested first, the wait is a counted one that leaves the stores in
+  // flight (the fp32-residual epilogue of a 256 x 256 tile used to be eight, then two, dependent load -> add -> store rounds).
+  // FULL tiles (no row remap, wholly inside M x N) run the same code without per-row branches, which is what lets hipcc count.
   constexpr bool RES_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS || EPI == EPI_BF16_LRELU_AFFINE);
   constexpr bool RES_BF16 = (EPI == EPI_BF16_ADD_RELU);
-#pragma unroll
-  for (int mt0 = 0; mt0 < MT; mt0 += GM) {
-    long orow_[GM];
-    bool ok_[GM];
-    float4 rf[GM][4];
-    uint4 rb[GM][2];
-    if (EPI != EPI_HEADS) {
+  constexpr int GM = (RES_F32 || RES_BF16) ? 2 : 4;
+  constexpr int NG = MT / GM;
+  struct Group {
+    long orow[GM];
+    bool ok[GM];
+    float4 rf[RES_F32 ? GM : 1][4];
+    uint4 rb[RES_BF16 ? GM : 1][2];
+  };
+  auto rows = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    auto request = [&](int mt0, Group& G) {
+      if (EPI == EPI_HEADS) return;
 #pragma unroll
       for (int g = 0; g < GM; g++) {
         const int m = m0 + wr * MT * 16 + (mt0 + g) * 16 + l15;
-        bool valid = false;
-        long orow = 0;
-        if (m < p.M) orow = remap_row(p, m, valid);
-        ok_[g] = valid; orow_[g] = orow;
-        if (RES_F32) {
+        bool valid = FULL;
+        long orow = m;
+        if (!FULL) { orow = 0; if (m < p.M) orow = remap_row(p, m, valid); }
+        G.ok[g] = valid; G.orow[g] = orow;
+        if constexpr (RES_F32) {
           const bool has = valid && (EPI != EPI_BF16_LRELU_AFFINE || p.resid != nullptr);
           if (has) {
             const long rrow = (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
             const float4* rp = (const float4*)(p.resid + rrow * p.ldr + nb);
 #pragma unroll
-            for (int i = 0; i < 4; i++) rf[g][i] = rp[i];
+            for (int i = 0; i < 4; i++) G.rf[g][i] = rp[i];
           } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) rf[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 4; i++) G.rf[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
-        if (RES_BF16) {
+        if constexpr (RES_BF16) {
           if (valid && p.resid_bf16) {
             const uint4* rp = (const uint4*)(p.resid_bf16 + orow * p.ldrb + nb);
-            rb[g][0] = rp[0]; rb[g][1] = rp[1];
+            G.rb[g][0] = rp[0]; G.rb[g][1] = rp[1];
           } else {
-            rb[g][0] = make_uint4(0, 0, 0, 0); rb[g][1] = make_uint4(0, 0, 0, 0);
+            G.rb[g][0] = make_uint4(0, 0, 0, 0); G.rb[g][1] = make_uint4(0, 0, 0, 0);
           }
         }
       }
-    }
+    };
+    auto finish = [&](int mt0, const Group& G) {
 #pragma unroll
-    for (int g = 0; g < GM; g++) {
-      const int mt = mt0 + g;
-      const int m = m0 + wr * MT * 16 + mt * 16 + l15;
-      if (m >= p.M) continue;
-      float v[16];
+      for (int g = 0; g < GM; g++) {
+        const int mt = mt0 + g;
+        const int m = m0 + wr * MT * 16 + mt * 16 + l15;
+        if (!FULL && m >= p.M) continue;
+        float v[16];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
+          for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
 
-      if (EPI == EPI_HEADS) {
-        const int blk = nb / p.d_model + p.first_block;
-        const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
-        const int b = m / p.S, s = m - b * p.S;
-        bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
-        bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
-        uint4 o0, o1;
-        o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-        o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-        o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-        o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-        ((uint4*)dst)[0] = o0;
-        ((uint4*)dst)[1] = o1;
-        continue;
-      }
+        if (EPI == EPI_HEADS) {
+          const int blk = nb / p.d_model + p.first_block;
+          const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
+          const int b = m / p.S, s = m - b * p.S;
+          bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
+          bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
+          uint4 o0, o1;
+          o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+          o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+          o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+          o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+          ((uint4*)dst)[0] = o0;
+          ((uint4*)dst)[1] = o1;
+          continue;
+        }
 
-      if (!ok_[g]) continue;
-      const long orow = orow_[g];
+        if (!FULL && !G.ok[g]) continue;
+        const long orow = G.orow[g];
 
-      if (EPI == EPI_BF16_LRELU_AFFINE) {
+        if constexpr (EPI == EPI_BF16_LRELU_AFFINE) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {     // zeros when there is no residual
-          v[4 * i + 0] += rf[g][i].x; v[4 * i + 1] += rf[g][i].y; v[4 * i + 2] += rf[g][i].z; v[4 * i + 3] += rf[g][i].w;
+          for (int i = 0; i < 4; i++) {     // zeros when there is no residual
+            v[4 * i + 0] += G.rf[g][i].x; v[4 * i + 1] += G.rf[g][i].y; v[4 * i + 2] += G.rf[g][i].z; v[4 * i + 3] += G.rf[g][i].w;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
+            const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
+            const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
+            v[i] = t * sc + sh;
+          }
         }
+        if constexpr (EPI == EPI_BF16_ADD_RELU) {
+          const uint32_t rw[8] = {G.rb[g][0].x, G.rb[g][0].y, G.rb[g][0].z, G.rb[g][0].w, G.rb[g][1].x, G.rb[g][1].y, G.rb[g][1].z, G.rb[g][1].w};
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
-          const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
-          const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
-          v[i] = t * sc + sh;
-        }
-      }
-      if (EPI == EPI_BF16_ADD_RELU) {
-        const uint32_t rw[8] = {rb[g][0].x, rb[g][0].y, rb[g][0].z, rb[g][0].w, rb[g][1].x, rb[g][1].y, rb[g][1].z, rb[g][1].w};
-#pragma unroll
-        for (int i = 0; i < 8; i++) {     // zeros when there is no residual
-          v[2 * i] += __uint_as_float(rw[i] << 16);
-          v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
-      }
-      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
-        if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-          for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
-        }
-        if (EPI == EPI_BF16_RELU) {
+          for (int i = 0; i < 8; i++) {     // zeros when there is no residual
+            v[2 * i] += __uint_as_float(rw[i] << 16);
+            v[2 * i + 1] += __uint_as_float(rw[i] & 0xffff0000u);
+          }
 #pragma unroll
           for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
         }
-        bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
-        uint4 o0, o1;
-        o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-        o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-        o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-        o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-        ((uint4*)dst)[0] = o0;
-        ((uint4*)dst)[1] = o1;
-      } else {
-        if (EPI == EPI_F32_GELU_POS) {
+        if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
+          if (EPI == EPI_BF16_GELU) {
 #pragma unroll
-          for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
-        }
-        if (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            v[4 * i + 0] += rf[g][i].x; v[4 * i + 1] += rf[g][i].y; v[4 * i + 2] += rf[g][i].z; v[4 * i + 3] += rf[g][i].w;
+            for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
           }
-        }
-        float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+          if (EPI == EPI_BF16_RELU) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
+          }
+          bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
+          uint4 o0, o1;
+          o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
+          o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
+          o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
+          o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
+          ((uint4*)dst)[0] = o0;
+          ((uint4*)dst)[1] = o1;
+        } else {
+          if (EPI == EPI_F32_GELU_POS) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
+          }
+          if constexpr (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              v[4 * i + 0] += G.rf[g][i].x; v[4 * i + 1] += G.rf[g][i].y; v[4 * i + 2] += G.rf[g][i].z; v[4 * i + 3] += G.rf[g][i].w;
+            }
+          }
+          float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+#pragma unroll
+          for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+        }
       }
+    };
+    Group G[2];
+    request(0, G[0]);
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0++) {
+      if (g0 + 1 < NG) request((g0 + 1) * GM, G[(g0 + 1) & 1]);
+      finish(g0 * GM, G[g0 & 1]);
     }
+  };
+  const bool full = p.rpb_in <= 0 && m0 + WM * MT * 16 <= p.M && n0 + WN * 64 <= p.N;
+  if (full) rows(std::true_type{});
+  else rows(std::false_type{});
+}
+
+// XCD-aware bijective remap (blocks b, b+8 share an XCD/L2): give each XCD a contiguous
+// run of tiles so the A row-panel and the (small) W are re-read from that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+  return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+}
+
+template <int EPI, int WM, int WN, int MT>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT == 4 ? 2 : 1) : 4) void gemm_bf16_nt_kernel(GemmParams p) {
+  constexpr int TBM = WM * MT * 16, TBN = WN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + TBN - 1) / TBN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  gemm_tile<EPI, WM, WN, MT>(p, smem, tm * TBM, tn * TBN, [](const GemmParams& pp, char* sm, int m0, int n0, f32x4 (&acc)[MT][4], auto swap) {
+    gemm_mainloop<decltype(swap)::value, WM, WN, MT>(pp, sm, m0, n0, acc);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, phased main loop (cdna_hip_programming.md "The 256^2 8-phase template"): same LDS image, swizzle keys,
+// fragment maps and epilogues as the kernel above; what changes is WHEN things are issued.
+//   * a K tile (64 KB: A 256 rows, W 256 rows) is staged as four 16 KB HALF-TILES: A-half a = the a-th 64 rows of each wave
+//     row's 128, W-half b = the 8-row groups of parity b (= accumulator columns j in {2b, 2b+1} of every wave column);
+//   * a K tile is consumed in four PHASES of 16 MFMAs per wave: (A0,W0) (A0,W1) (A1,W1) (A1,W0), each phase = [LDS reads of the
+//     operand half it is the first to need + ONE half-tile prefetch] barrier [MFMAs] barrier;
+//   * the prefetch runs 3 half-tiles ahead and stays in flight ACROSS the barriers: one counted `s_waitcnt vmcnt(6)` per K tile
+//     (phase 4), never 0 inside the loop;
+//   * the two wave rows (one wave of each per SIMD) run ONE BARRIER APART, so that a SIMD's matrix core works for one wave
+//     while the other wave issues its reads and prefetches.
+// Hazards, with barrier b_n the n-th barrier of wave row 0 (row 1 passes it as its (n+1)-th call), phase g = [L(g)] b_2g [M(g)]
+// b_2g+1 for row 0 and [L(g)] b_2g+1 [M(g)] b_2g+2 for row 1:
+//   RAW  a half-tile waited for (every wave: its own two DMA instructions) in L(g) is complete and visible after b_2g+1;
+//        both rows read it in L(g+1) or later.  Tile t+1 is waited for in phase 4 of tile t and first read in phase 1 of t+1.
+//   WAR  the reads of phase g are complete (lgkmcnt(0) before the MFMAs) before b_2g+1 in row 0 and before b_2g+2 in row 1;
+//        row 0 restages in L(g') after b_2g'-1, so a slot BOTH rows read (W halves) is restaged two phases after its last read;
+//        a slot only the staging row reads (A halves: a wave stages rows of its own wave row) one phase after.
+//   Stage schedule (slot <- half-tile): phase 1 of tile t: A1(t+1); phase 2: A0(t+2); phase 3: W0(t+2); phase 4: W1(t+2).
+//   Last reads: A0, W0 phase 1; W1 phase 2; A1 phase 3.
+template <bool SWAP>
+__device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[8][4]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- per-lane DMA sources: [half][instruction]; an instruction fills 8 LDS rows (1 KB) ----
+  const bf16_t* srcA[2][2];
+  const bf16_t* srcB[2][2];
+  int dstA[2][2], dstB[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int r0 = wr * 128 + a * 64 + wc * 16 + i * 8;
+      const int r = r0 + (lane >> 3);
+      int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+      srcA[a][i] = p.A + (long)gm * p.lda + (((lane & 7) ^ keyA(r)) << 3);
+      dstA[a][i] = r0 * 128;
+      const int g8 = 2 * (2 * wave + i) + a;            // 8-row group of W-half a
+      const int rb = g8 * 8 + (lane >> 3);
+      int gn = n0 + rb; gn = gn < p.N ? gn : p.N - 1;
+      srcB[a][i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyB(rb)) << 3);
+      dstB[a][i] = 32768 + g8 * 1024;
+    }
+  const int kt_per_tap = p.K / BK;
+  const int nt = kt_per_tap * (p.ntaps > 1 ? p.ntaps : 1);
+  // element offset of K tile t in a row of A: taps are shifted views of A (a_tap_stride apart), kt_per_tap tiles each
+  auto a_koff = [&](int t) -> long {
+    const int tap = t / kt_per_tap;
+    return (long)(t - tap * kt_per_tap) * BK + (long)tap * p.a_tap_stride;
+  };
+  auto stage_a = [&](int t, long ka, int a) {
+    char* buf = smem + (t & 1) * 65536;
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcA[a][0] + ka), (lptr_t)(buf + dstA[a][0]), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcA[a][1] + ka), (lptr_t)(buf + dstA[a][1]), 16, 0, 0);
+  };
+  auto stage_b = [&](int t, int b) {
+    char* buf = smem + (t & 1) * 65536;
+    const int kw = t * BK;
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcB[b][0] + kw), (lptr_t)(buf + dstB[b][0]), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(srcB[b][1] + kw), (lptr_t)(buf + dstB[b][1]), 16, 0, 0);
+  };
+
+  // ---- per-lane LDS read offsets (as in gemm_mainloop) ----
+  const int l15 = lane & 15, h = lane >> 4;
+  const int ka_ = keyA(l15);
+  const int q = l15 >> 2, u = l15 & 3;
+  const int kb_ = ((u >> 1) & 1) | (q << 1);
+  int offA[2], offB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    offA[ks] = (wr * 128 + l15) * 128 + (((4 * ks + h) ^ ka_) << 4);
+    offB[ks] = 32768 + (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb_) << 4);
   }
+
+  // ---- prologue: tile 0 and three half-tiles of tile 1 in flight; tile 0 landed and visible to everybody ----
+  long ka1 = nt > 1 ? a_koff(1) : 0;           // of tile t+1 and t+2 inside the loop: advanced without a division there
+  long ka2 = nt > 2 ? a_koff(2) : 0;
+  int kk2 = nt > 2 ? 2 % kt_per_tap : 0;
+  stage_a(0, 0, 0); stage_b(0, 0); stage_b(0, 1); stage_a(0, 0, 1);
+  if (nt > 1) {
+    stage_a(1, ka1, 0); stage_b(1, 0); stage_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // wave row 1 runs one barrier behind from here on
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define CCX_PHASE_MFMA(MT0, J0, FB)                                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                          \
+  _Pragma("unroll") for (int m = 0; m < 4; m++)                                                             \
+  _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                        \
+    if (SWAP) acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[jj][ks], fa[m][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
+    else      acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][ks], FB[jj][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
+  }                                                                                                         \
+  __builtin_amdgcn_s_setprio(0);                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                        \
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nt; t++) {
+    const char* buf = smem + (t & 1) * 65536;
+    // phase 1: W0 and A0 fragments; prefetch A1(t+1)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) fb0[jj][ks] = *(const bf16x8*)(buf + offB[ks] + jj * 4 * 128);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int m = 0; m < 4; m++) fa[m][ks] = *(const bf16x8*)(buf + offA[ks] + m * 16 * 128);
+    if (t + 1 < nt) stage_a(t + 1, ka1, 1);
+    CCX_PHASE_MFMA(0, 0, fb0)
+    // phase 2: W1 fragments; prefetch A0(t+2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) fb1[jj][ks] = *(const bf16x8*)(buf + offB[ks] + (2 + jj) * 4 * 128);
+    if (t + 2 < nt) stage_a(t + 2, ka2, 0);
+    CCX_PHASE_MFMA(0, 2, fb1)
+    // phase 3: A1 fragments; prefetch W0(t+2)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int m = 0; m < 4; m++) fa[m][ks] = *(const bf16x8*)(buf + offA[ks] + (4 + m) * 16 * 128);
+    if (t + 2 < nt) stage_b(t + 2, 0);
+    CCX_PHASE_MFMA(4, 2, fb1)
+    // phase 4: W0 fragments are still in registers; prefetch W1(t+2); tile t+1 must have landed before phase 1 of t+1
+    if (t + 2 < nt) {
+      stage_b(t + 2, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CCX_PHASE_MFMA(4, 0, fb0)
+    ka1 = ka2;
+    kk2++;
+    if (kk2 == kt_per_tap) { kk2 = 0; ka2 += BK + p.a_tap_stride - (long)kt_per_tap * BK; }
+    else ka2 += BK;
+  }
+#undef CCX_PHASE_MFMA
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // pairs with wave row 1's last barrier
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_phased_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + 255) / 256;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  gemm_tile<EPI, 2, 4, 8>(p, smem, tm * 256, tn * 256, [](const GemmParams& pp, char* sm, int m0, int n0, f32x4 (&acc)[8][4], auto swap) {
+    gemm_mainloop_phased<decltype(swap)::value>(pp, sm, m0, n0, acc);
+  });
 }
 
 template <int EPI, int WM, int WN, int MT>
@@ -355,6 +559,34 @@ static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream)
 }
 
 template <int EPI>
+static int launch_phased(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 131072;
+  const int tiles = ccx_cdiv(p.M, 256) * ccx_cdiv(p.N, 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_phased_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  {
+    const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;
+    const double kt = (double)p.K * (p.ntaps > 1 ? p.ntaps : 1);
+    static const bool by_shape = getenv("CCX_PROF_SHAPES") != nullptr;
+    const char* label = "gemm_bf16_nt_kernel";
+    if (by_shape && ctx->prof_on) {
+      static std::map<std::string, std::string> names;
+      char buf[160];
+      snprintf(buf, sizeof(buf), "gemm<epi%d,256x256> M=%d N=%d K=%d taps=%d", EPI, p.M, p.N, p.K, p.ntaps > 1 ? p.ntaps : 1);
+      label = names.emplace(buf, buf).first->second.c_str();
+    }
+    ccx_prof_scope ps(ctx, stream, label, 2.0 * p.M * (double)p.N * kt,
+                      2.0 * ((double)p.M * p.K + (double)p.N * kt) + obytes * p.M * (double)p.N);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<EPI>), dim3(tiles), dim3(512), LDS, stream, p);
+  }
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+template <int EPI>
 static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   // 256x256 tiles once there are enough of them to fill the 256 CUs and N is wide enough not to waste half a tile;
   // the 128x128 kernel (2 blocks per CU) otherwise.  CCX_GEMM_TILE=128|256 forces one for A/B measurements.
@@ -363,7 +595,11 @@ static int launch_epi(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   bool fits = p.N >= 256 && (p.N % 256 == 0 || p.N >= 1024);
   if (EPI == EPI_HEADS) fits = fits && p.N % 256 == 0 && p.d_model % 256 == 0;
   const bool big = fits && (forced == 256 || (forced != 128 && big_tiles >= 224));
-  if (big) return launch_epi_geo<EPI, 2, 4, 8>(ctx, p, stream);
+  if (big) {
+    static const bool phased = [] { const char* e = getenv("CCX_GEMM_PHASED"); return e ? atoi(e) != 0 : true; }();
+    if (phased) return launch_phased<EPI>(ctx, p, stream);
+    return launch_epi_geo<EPI, 2, 4, 8>(ctx, p, stream);
+  }
   // narrow layers (ResNet 32/64 channels, SincNet 60): 256 x 64 tiles, 4 waves of 64 rows (80 KB LDS, 2 blocks per CU).
   // Measured over the ResNet-34 convolutions: 128 x 64 / 2 waves 59.6 ms per step, 128 x 64 / 4 waves 51.6, 256 x 64 49.9.
   if (EPI != EPI_HEADS && p.N <= 64 && forced == 0) return launch_epi_geo<EPI, 4, 1, 4>(ctx, p, stream);

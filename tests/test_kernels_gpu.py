@@ -18,7 +18,9 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1500, 768, 768), (12000, 2304, 768), (77, 384, 3072)])
+# the last four rows take the phased 256 x 256 kernel (>= 224 tiles) with 1, 2, 3 and 12 K tiles, ragged M and a ragged last column tile
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1500, 768, 768), (12000, 2304, 768), (77, 384, 3072),
+                                   (16384, 1024, 64), (16300, 1024, 128), (14500, 1280, 192), (15000, 1104, 768)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 5])
 def test_gemm_bf16(ccx_ctx, M, N, K, epi):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + epi)
@@ -48,6 +50,32 @@ def test_gemm_bf16(ccx_ctx, M, N, K, epi):
     # element-wise: identical inputs, fp32 accumulate -> only summation order / output rounding differ
     atol = 0.05 if out_dtype == torch.bfloat16 else 2e-3
     assert float((got - ref).abs().max()) < atol
+
+
+@pytest.mark.parametrize("epi", [1, 2])
+def test_gemm_phased_repeatable(ccx_ctx, epi):
+    """The phased main loop keeps LDS-DMA in flight across barriers: a misplaced wait shows as a tile that differs from run to
+    run.  40 launches of an encoder-shaped problem (K = 768 and 3072) must be bit-identical, and right."""
+    for (M, N, K) in [(36000, 3072, 768), (36000, 768, 3072)]:
+        g = torch.Generator().manual_seed(N + epi)
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        resid = torch.randn(M, N, generator=g).cuda()
+        out_dtype = torch.bfloat16 if epi == 1 else torch.float32
+        ref = A.float() @ W.float().T + bias
+        ref = torch.nn.functional.gelu(ref) if epi == 1 else ref + resid
+        first = None
+        for it in range(40):
+            out = torch.full((M, N), float("nan"), dtype=out_dtype, device="cuda")
+            rc = ccx_ctx.lib.ccx_gemm_bf16(ccx_ctx.handle, epi, A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), out.data_ptr(), N,
+                                           resid.data_ptr() if epi == 2 else None, N, M, N, K, _stream())
+            ccx_ctx.check(rc, "gemm")
+            if first is None:
+                first = out
+                assert _rel(out.float(), ref) < (6e-3 if epi == 1 else 2e-5)
+            else:
+                assert torch.equal(out, first), f"launch {it} differs from launch 0"
 
 
 def test_gemm_rejects_bad_k(ccx_ctx):
