@@ -9,15 +9,22 @@
 // conflict-free.
 //
 // The MFMA is issued with operands swapped (W fragment as "A", activation fragment as "B"),
-// so the accumulator holds C^T: each lane owns ONE output row and -- thanks to a row
-// permutation applied when reading W from LDS -- 16 CONSECUTIVE output columns.  The
-// epilogue therefore writes 32 B (bf16) / 64 B (f32) contiguous per lane with no LDS
-// round trip.  For V^T destinations (EPI_HEADS, v_transposed) the un-swapped order is used
-// so each lane owns 4 consecutive ROWS of one column instead.
+// so the accumulator holds C^T: each lane owns ONE output row, and a row permutation applied when
+// reading W from LDS decides WHICH columns.  The map is chosen per output type so that one store
+// INSTRUCTION writes 64 contiguous bytes per row (tools/microbench_store.hip: a tile store whose
+// lanes each own 64 contiguous bytes -- 16-byte pieces at a 64-byte pitch per instruction -- reaches
+// 3.4 TB/s, the same bytes with the four lanes of a row side by side 5.2 TB/s):
+//   CM 1 (fp32 out): lane (l15, h) owns columns 16 j + 4 h + r        -> one float4 per accumulator j,
+//   CM 2 (bf16 out): lane owns columns 32 (j >> 1) + 8 h + 4 (j & 1) + r -> one uint4 (8 bf16) per accumulator pair.
+// For V^T destinations (EPI_HEADS, v_transposed) the un-swapped order is used, so each lane owns 4
+// consecutive ROWS of one column instead.
 #include <map>
 #include <string>
 #include "gemm_bf16.h"
 
+#ifndef CCX_GEMM_SETPRIO
+#define CCX_GEMM_SETPRIO 1
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -27,14 +34,26 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int keyA(int r) { return (r >> 1) & 7; }
-__device__ __forceinline__ int keyB(int r) { return ((r >> 1) & 1) | (((r >> 4) & 3) << 1); }
+// W rows: row (0..63 inside a wave column) read by the lanes with l15 = i for accumulator j, and the swizzle key of a row.
+// Both keys are conflict-free for the 16 rows one ds_read_b128 touches (tools/lds_bank_sim.py) and do not depend on j.
+template <int CM> __device__ __forceinline__ int w_row(int j, int i) {
+  return CM == 1 ? 16 * j + i : 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3);
+}
+template <int CM> __device__ __forceinline__ int keyW(int r) {
+  return CM == 1 ? (r >> 1) & 7 : ((r >> 1) & 1) | (((r >> 3) & 1) << 1) | (((r >> 4) & 1) << 2);
+}
+// first of the 4 consecutive columns (inside the wave's 64) that accumulator j holds in a lane of quarter h
+template <int CM> __device__ __forceinline__ int col4(int j, int h) {
+  return CM == 1 ? 16 * j + 4 * h : 32 * (j >> 1) + 8 * h + 4 * (j & 1);
+}
+constexpr int colmap_of(int epi) { return (epi == EPI_F32 || epi == EPI_F32_RESID || epi == EPI_F32_GELU_POS) ? 1 : 2; }
 
 // Block geometry: WM x WN waves, each wave owns (MT*16) x 64 outputs as MT x 4 accumulators.
 //   <2,2,4>: 128x128 tile, 4 waves, 64 KB LDS (2 stages) -> 2 blocks per CU        (64 flop per LDS-DMA byte)
 //   <2,4,8>: 256x256 tile, 8 waves, 128 KB LDS (2 stages) -> 1 block per CU        (128 flop per LDS-DMA byte)
 // The encoder GEMMs (K = 768) are bound by the L2 -> LDS operand stream, not by HBM or MFMA issue, so the
 // large tile is used whenever it still yields enough tiles to fill the 256 CUs.
-template <bool SWAP, int WM, int WN, int MT>
+template <bool SWAP, int CM, int WM, int WN, int MT>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[MT][4]) {
   constexpr int NW = WM * WN;
   constexpr int A_ROWS = WM * MT * 16, B_ROWS = WN * 64;
@@ -57,7 +76,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
   for (int i = 0; i < NB; i++) {
     const int r = (wave * NB + i) * 8 + (lane >> 3);
     int gn = n0 + r; gn = gn < p.N ? gn : p.N - 1;
-    srcB[i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyB(r)) << 3);
+    srcB[i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyW<CM>(r)) << 3);
   }
   const int kt_per_tap = p.K / BK;
   auto stage = [&](int t, int buf) {
@@ -77,13 +96,12 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
   // ---- per-lane LDS read offsets ----
   const int l15 = lane & 15, h = lane >> 4;
   const int ka = keyA(l15);                       // rows wr*MT*16 + mt*16 + l15
-  const int q = l15 >> 2, u = l15 & 3;
-  const int kb = ((u >> 1) & 1) | (q << 1);       // rows wc*64 + 16q + 4j + u
+  const int kb = keyW<CM>(w_row<CM>(0, l15));     // rows wc*64 + w_row(j, l15): the key is the same for every j
   int offA[2], offB[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
     offA[ks] = (wr * MT * 16 + l15) * 128 + (((4 * ks + h) ^ ka) << 4);
-    offB[ks] = (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb) << 4);
+    offB[ks] = (wc * 64 + w_row<CM>(0, l15)) * 128 + (((4 * ks + h) ^ kb) << 4);
   }
 
   const int nt = kt_per_tap * (p.ntaps > 1 ? p.ntaps : 1);
@@ -98,7 +116,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, char* smem, i
     for (int ks = 0; ks < 2; ks++) {
       bf16x8 b[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = *(const bf16x8*)(sB + offB[ks] + j * 4 * 128);
+      for (int j = 0; j < 4; j++) b[j] = *(const bf16x8*)(sB + offB[ks] + w_row<CM>(j, 0) * 128);
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) {
         const bf16x8 a = *(const bf16x8*)(sA + offA[ks] + mt * 16 * 128);
@@ -128,13 +146,16 @@ __device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& vali
   return (long)g * p.rpb_out + i + p.roff;
 }
 
-// Epilogue of one output tile: `acc` as left by a SWAP main loop (lane: one output row, 16 consecutive columns), or by the
-// un-swapped one for V^T destinations.  MAINLOOP is a functor (p, smem, m0, n0, acc, swap_tag).
+// One output tile: main loop (a functor (p, smem, m0, n0, acc, swap_tag)) and epilogue.  `acc` as left by a SWAP main loop --
+// lane (l15, h): output row l15 of each row tile, accumulator j = the 4 columns col4(j, h) .. +3 of the wave's 64 -- or by the
+// un-swapped one for V^T destinations.
 template <int EPI, int WM, int WN, int MT, typename MainLoop>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, MainLoop mainloop) {
+  constexpr int CM = colmap_of(EPI);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int l15 = lane & 15, h = lane >> 4;
+  const int cb = n0 + wc * 64;                    // first column of the wave's 64
 
   f32x4 acc[MT][4];
 #pragma unroll
@@ -146,11 +167,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     const int blk = n0 / p.d_model + p.first_block;  // 0=q 1=k 2=v  (d_model % 128 == 0)
     if (blk == 2 && p.v_transposed) {
       mainloop(p, smem, m0, n0, acc, std::false_type{});
-      // lane: column n = n0 + wc*64 + 16q + 4j + u ; rows m0 + wr*64 + mt*16 + 4h + reg
-      const int q = l15 >> 2, u = l15 & 3;
+      // lane: column n = cb + w_row(j, l15) ; rows m0 + wr*MT*16 + mt*16 + 4h + reg
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int n = n0 + wc * 64 + 16 * q + 4 * j + u;
+        const int n = cb + w_row<CM>(j, l15);
         const int nn = n % p.d_model, hh = nn >> 6, d = nn & 63;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
@@ -172,22 +192,27 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 
   mainloop(p, smem, m0, n0, acc, std::true_type{});
 
-  // lane: row m = m0 + wr*64 + mt*16 + l15 ; columns nb .. nb+15, value index 4j+reg
-  const int nb = n0 + wc * 64 + 16 * h;
-  if (EPI != EPI_HEADS && nb >= p.N) return;   // this lane's 16 columns lie wholly past N (narrow layers)
+  // columns past N rounded up to 16 are not written (the destination has that many, see gemm_bf16.h); 4- and 8-wide groups
+  // start on multiples of 4 / 8, so a group lies wholly on one side
+  const int Nw = (p.N + 15) & ~15;
+  if (EPI != EPI_HEADS && cb >= Nw) return;       // the wave's 64 columns lie wholly past N (narrow layers)
+  int c4[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) c4[j] = cb + col4<CM>(j, h);
   float bias[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) bias[i] = 0.f;
   if (p.bias) {
-    if (nb + 16 <= p.N && ((uintptr_t)p.bias & 15) == 0) {
+    const bool al = ((uintptr_t)p.bias & 15) == 0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float4 b4 = ((const float4*)(p.bias + nb))[i];
-        bias[4 * i] = b4.x; bias[4 * i + 1] = b4.y; bias[4 * i + 2] = b4.z; bias[4 * i + 3] = b4.w;
+    for (int j = 0; j < 4; j++) {
+      if (al && c4[j] + 4 <= p.N) {
+        const float4 b4 = *(const float4*)(p.bias + c4[j]);
+        bias[4 * j] = b4.x; bias[4 * j + 1] = b4.y; bias[4 * j + 2] = b4.z; bias[4 * j + 3] = b4.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) bias[4 * j + r] = (c4[j] + r < p.N) ? p.bias[c4[j] + r] : 0.f;
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; i++) bias[i] = (nb + i < p.N) ? p.bias[nb + i] : 0.f;
     }
   }
   // Consume the bias HERE, in straight-line code: hipcc otherwise waits for it with a `vmcnt(0)` at the head of every row
@@ -203,7 +228,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
   // FULL tiles (no row remap, wholly inside M x N) run the same code without per-row branches, which is what lets hipcc count.
   constexpr bool RES_F32 = (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS || EPI == EPI_BF16_LRELU_AFFINE);
   constexpr bool RES_BF16 = (EPI == EPI_BF16_ADD_RELU);
-  constexpr int GM = (RES_F32 || RES_BF16) ? 2 : 4;
+  constexpr bool OUT_BF16 = CM == 2;
+  constexpr int GM = EPI == EPI_BF16_LRELU_AFFINE ? 1 : (RES_F32 || RES_BF16) ? 2 : 4;   // (the affine epilogue is short of registers)
   constexpr int NG = MT / GM;
   struct Group {
     long orow[GM];
@@ -224,22 +250,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
         G.ok[g] = valid; G.orow[g] = orow;
         if constexpr (RES_F32) {
           const bool has = valid && (EPI != EPI_BF16_LRELU_AFFINE || p.resid != nullptr);
-          if (has) {
-            const long rrow = (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
-            const float4* rp = (const float4*)(p.resid + rrow * p.ldr + nb);
+          const long rrow = (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
 #pragma unroll
-            for (int i = 0; i < 4; i++) G.rf[g][i] = rp[i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) G.rf[g][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int j = 0; j < 4; j++) {
+            if (has && (FULL || c4[j] < Nw)) G.rf[g][j] = *(const float4*)(p.resid + rrow * p.ldr + c4[j]);
+            else G.rf[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
         if constexpr (RES_BF16) {
-          if (valid && p.resid_bf16) {
-            const uint4* rp = (const uint4*)(p.resid_bf16 + orow * p.ldrb + nb);
-            G.rb[g][0] = rp[0]; G.rb[g][1] = rp[1];
-          } else {
-            G.rb[g][0] = make_uint4(0, 0, 0, 0); G.rb[g][1] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            if (valid && p.resid_bf16 && (FULL || c4[2 * i] < Nw)) G.rb[g][i] = *(const uint4*)(p.resid_bf16 + orow * p.ldrb + c4[2 * i]);
+            else G.rb[g][i] = make_uint4(0, 0, 0, 0);
           }
         }
       }
@@ -257,18 +279,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
           for (int r = 0; r < 4; r++) v[4 * j + r] = acc[mt][j][r] + bias[4 * j + r];
 
         if (EPI == EPI_HEADS) {
-          const int blk = nb / p.d_model + p.first_block;
-          const int nn = nb % p.d_model, hh = nn >> 6, d = nn & 63;
+          // the wave's 64 columns are one head of one of q / k / v (d_model % 128 == 0, cb % 64 == 0)
+          const int blk = cb / p.d_model + p.first_block;
+          const int hh = (cb % p.d_model) >> 6;
           const int b = m / p.S, s = m - b * p.S;
           bf16_t* base = blk == 0 ? p.hq : (blk == 1 ? p.hk : p.hv);
-          bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64 + d;
-          uint4 o0, o1;
-          o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-          o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-          o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-          o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-          ((uint4*)dst)[0] = o0;
-          ((uint4*)dst)[1] = o1;
+          bf16_t* dst = base + ((long)(b * p.n_head + hh) * p.Spad + s) * 64;
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            uint4 o;
+            o.x = pack_bf16x2(v[8 * i], v[8 * i + 1]);     o.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
+            o.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); o.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
+            *(uint4*)(dst + (c4[2 * i] - cb)) = o;
+          }
           continue;
         }
 
@@ -277,16 +300,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 
         if constexpr (EPI == EPI_BF16_LRELU_AFFINE) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) {     // zeros when there is no residual
-            v[4 * i + 0] += G.rf[g][i].x; v[4 * i + 1] += G.rf[g][i].y; v[4 * i + 2] += G.rf[g][i].z; v[4 * i + 3] += G.rf[g][i].w;
+          for (int j = 0; j < 4; j++) {     // zeros when there is no residual
+            v[4 * j + 0] += G.rf[g][j].x; v[4 * j + 1] += G.rf[g][j].y; v[4 * j + 2] += G.rf[g][j].z; v[4 * j + 3] += G.rf[g][j].w;
           }
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
-            float t = v[i] >= 0.f ? v[i] : p.slope * v[i];
-            const float sc = (p.scale && nb + i < p.N) ? p.scale[nb + i] : 1.f;
-            const float sh = (p.shift && nb + i < p.N) ? p.shift[nb + i] : 0.f;
-            v[i] = t * sc + sh;
-          }
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int c = c4[j] + r;
+              float t = v[4 * j + r] >= 0.f ? v[4 * j + r] : p.slope * v[4 * j + r];
+              const float sc = (p.scale && c < p.N) ? p.scale[c] : 1.f;
+              const float sh = (p.shift && c < p.N) ? p.shift[c] : 0.f;
+              v[4 * j + r] = t * sc + sh;
+            }
         }
         if constexpr (EPI == EPI_BF16_ADD_RELU) {
           const uint32_t rw[8] = {G.rb[g][0].x, G.rb[g][0].y, G.rb[g][0].z, G.rb[g][0].w, G.rb[g][1].x, G.rb[g][1].y, G.rb[g][1].z, G.rb[g][1].w};
@@ -298,7 +324,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
           for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
         }
-        if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_BF16_RELU || EPI == EPI_BF16_LRELU_AFFINE || EPI == EPI_BF16_ADD_RELU) {
+        if constexpr (OUT_BF16) {
           if (EPI == EPI_BF16_GELU) {
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = gelu_erf(v[i]);
@@ -307,14 +333,15 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.f);
           }
-          bf16_t* dst = (bf16_t*)p.out + orow * p.ldo + nb;
-          uint4 o0, o1;
-          o0.x = pack_bf16x2(v[0], v[1]);   o0.y = pack_bf16x2(v[2], v[3]);
-          o0.z = pack_bf16x2(v[4], v[5]);   o0.w = pack_bf16x2(v[6], v[7]);
-          o1.x = pack_bf16x2(v[8], v[9]);   o1.y = pack_bf16x2(v[10], v[11]);
-          o1.z = pack_bf16x2(v[12], v[13]); o1.w = pack_bf16x2(v[14], v[15]);
-          ((uint4*)dst)[0] = o0;
-          ((uint4*)dst)[1] = o1;
+          bf16_t* dst = (bf16_t*)p.out + orow * p.ldo;
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            if (!FULL && c4[2 * i] >= Nw) continue;
+            uint4 o;
+            o.x = pack_bf16x2(v[8 * i], v[8 * i + 1]);     o.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
+            o.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); o.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
+            *(uint4*)(dst + c4[2 * i]) = o;
+          }
         } else {
           if (EPI == EPI_F32_GELU_POS) {
 #pragma unroll
@@ -322,13 +349,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
           }
           if constexpr (EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-              v[4 * i + 0] += G.rf[g][i].x; v[4 * i + 1] += G.rf[g][i].y; v[4 * i + 2] += G.rf[g][i].z; v[4 * i + 3] += G.rf[g][i].w;
+            for (int j = 0; j < 4; j++) {
+              v[4 * j + 0] += G.rf[g][j].x; v[4 * j + 1] += G.rf[g][j].y; v[4 * j + 2] += G.rf[g][j].z; v[4 * j + 3] += G.rf[g][j].w;
             }
           }
-          float4* dst = (float4*)((float*)p.out + orow * p.ldo + nb);
+          float* dst = (float*)p.out + orow * p.ldo;
 #pragma unroll
-          for (int i = 0; i < 4; i++) dst[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+          for (int j = 0; j < 4; j++) {
+            if (!FULL && c4[j] >= Nw) continue;
+            *(float4*)(dst + c4[j]) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+          }
         }
       }
     };
@@ -360,7 +390,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
   gemm_tile<EPI, WM, WN, MT>(p, smem, tm * TBM, tn * TBN, [](const GemmParams& pp, char* sm, int m0, int n0, f32x4 (&acc)[MT][4], auto swap) {
-    gemm_mainloop<decltype(swap)::value, WM, WN, MT>(pp, sm, m0, n0, acc);
+    gemm_mainloop<decltype(swap)::value, colmap_of(EPI), WM, WN, MT>(pp, sm, m0, n0, acc);
   });
 }
 
@@ -368,7 +398,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
 // 256 x 256 tile, phased main loop (cdna_hip_programming.md "The 256^2 8-phase template"): same LDS image, swizzle keys,
 // fragment maps and epilogues as the kernel above; what changes is WHEN things are issued.
 //   * a K tile (64 KB: A 256 rows, W 256 rows) is staged as four 16 KB HALF-TILES: A-half a = the a-th 64 rows of each wave
-//     row's 128, W-half b = the 8-row groups of parity b (= accumulator columns j in {2b, 2b+1} of every wave column);
+//     row's 128, W-half b = rows 32 b .. 32 b + 31 of every wave column's 64 (= accumulators j in {2b, 2b+1});
 //   * a K tile is consumed in four PHASES of 16 MFMAs per wave: (A0,W0) (A0,W1) (A1,W1) (A1,W0), each phase = [LDS reads of the
 //     operand half it is the first to need + ONE half-tile prefetch] barrier [MFMAs] barrier;
 //   * the prefetch runs 3 half-tiles ahead and stays in flight ACROSS the barriers: one counted `s_waitcnt vmcnt(6)` per K tile
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 4 ? (WM * WN) / 4 * (MT 
 //        a slot only the staging row reads (A halves: a wave stages rows of its own wave row) one phase after.
 //   Stage schedule (slot <- half-tile): phase 1 of tile t: A1(t+1); phase 2: A0(t+2); phase 3: W0(t+2); phase 4: W1(t+2).
 //   Last reads: A0, W0 phase 1; W1 phase 2; A1 phase 3.
-template <bool SWAP>
+template <bool SWAP, int CM>
 __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* smem, int m0, int n0, f32x4 (&acc)[8][4]) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,10 +433,11 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
       int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
       srcA[a][i] = p.A + (long)gm * p.lda + (((lane & 7) ^ keyA(r)) << 3);
       dstA[a][i] = r0 * 128;
-      const int g8 = 2 * (2 * wave + i) + a;            // 8-row group of W-half a
+      const int x = 2 * wave + i;                       // W-half a = rows 32 a .. 32 a + 31 of every wave column's 64
+      const int g8 = 8 * (x >> 2) + 4 * a + (x & 3);    // 8-row group
       const int rb = g8 * 8 + (lane >> 3);
       int gn = n0 + rb; gn = gn < p.N ? gn : p.N - 1;
-      srcB[a][i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyB(rb)) << 3);
+      srcB[a][i] = p.W + (long)gn * p.ldw + (((lane & 7) ^ keyW<CM>(rb)) << 3);
       dstB[a][i] = 32768 + g8 * 1024;
     }
   const int kt_per_tap = p.K / BK;
@@ -431,13 +462,12 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
   // ---- per-lane LDS read offsets (as in gemm_mainloop) ----
   const int l15 = lane & 15, h = lane >> 4;
   const int ka_ = keyA(l15);
-  const int q = l15 >> 2, u = l15 & 3;
-  const int kb_ = ((u >> 1) & 1) | (q << 1);
+  const int kb_ = keyW<CM>(w_row<CM>(0, l15));
   int offA[2], offB[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
     offA[ks] = (wr * 128 + l15) * 128 + (((4 * ks + h) ^ ka_) << 4);
-    offB[ks] = 32768 + (wc * 64 + 16 * q + u) * 128 + (((4 * ks + h) ^ kb_) << 4);
+    offB[ks] = 32768 + (wc * 64 + w_row<CM>(0, l15)) * 128 + (((4 * ks + h) ^ kb_) << 4);
   }
 
   // ---- prologue: tile 0 and three half-tiles of tile 1 in flight; tile 0 landed and visible to everybody ----
@@ -460,14 +490,14 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
   __builtin_amdgcn_s_barrier();                                                                             \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                            \
+  if (CCX_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
   _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                          \
   _Pragma("unroll") for (int m = 0; m < 4; m++)                                                             \
   _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                        \
     if (SWAP) acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[jj][ks], fa[m][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
     else      acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][ks], FB[jj][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
   }                                                                                                         \
-  __builtin_amdgcn_s_setprio(0);                                                                            \
+  if (CCX_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                        \
   __builtin_amdgcn_s_barrier();
 
@@ -477,7 +507,7 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int jj = 0; jj < 2; jj++) fb0[jj][ks] = *(const bf16x8*)(buf + offB[ks] + jj * 4 * 128);
+      for (int jj = 0; jj < 2; jj++) fb0[jj][ks] = *(const bf16x8*)(buf + offB[ks] + w_row<CM>(jj, 0) * 128);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
@@ -489,7 +519,7 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int jj = 0; jj < 2; jj++) fb1[jj][ks] = *(const bf16x8*)(buf + offB[ks] + (2 + jj) * 4 * 128);
+      for (int jj = 0; jj < 2; jj++) fb1[jj][ks] = *(const bf16x8*)(buf + offB[ks] + w_row<CM>(2 + jj, 0) * 128);
     if (t + 2 < nt) stage_a(t + 2, ka2, 0);
     CCX_PHASE_MFMA(0, 2, fb1)
     // phase 3: A1 fragments; prefetch W0(t+2)
@@ -523,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_phased_kernel(GemmParams p) 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
   gemm_tile<EPI, 2, 4, 8>(p, smem, tm * 256, tn * 256, [](const GemmParams& pp, char* sm, int m0, int n0, f32x4 (&acc)[8][4], auto swap) {
-    gemm_mainloop_phased<decltype(swap)::value>(pp, sm, m0, n0, acc);
+    gemm_mainloop_phased<decltype(swap)::value, colmap_of(EPI)>(pp, sm, m0, n0, acc);
   });
 }
 

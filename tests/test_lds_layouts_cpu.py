@@ -14,16 +14,33 @@ def _perm_row(l15, j):
 
 
 def test_gemm_operand_reads_are_conflict_free():
-    # csrc/gemm_bf16.hip: 128-byte rows; A rows natural with keyA, W rows permuted with keyB; chunk = 4 ks + h
+    # csrc/gemm_bf16.hip: 128-byte rows; A rows natural with keyA; W rows in the map of the output type (w_row<CM>) with
+    # keyW<CM>; chunk = 4 ks + h
     key_a = lambda r: (r >> 1) & 7
-    key_b = lambda r: ((r >> 1) & 1) | (((r >> 4) & 3) << 1)
+    w_row = {1: lambda j, i: 16 * j + i,
+             2: lambda j, i: 32 * (j >> 1) + 8 * (i >> 2) + 4 * (j & 1) + (i & 3)}
+    key_w = {1: lambda r: (r >> 1) & 7,
+             2: lambda r: ((r >> 1) & 1) | (((r >> 3) & 1) << 1) | (((r >> 4) & 1) << 2)}
     for ks in range(2):
         a = [(l & 15) * 128 + (((4 * ks + (l >> 4)) ^ key_a(l & 15)) << 4) for l in range(64)]
         assert conflicts_b128(a)[0] == 1
+        for cm in (1, 2):
+            for j in range(4):
+                rows = [w_row[cm](j, l & 15) for l in range(64)]
+                # the kernel computes the key once, from the rows of j = 0
+                assert all(key_w[cm](rows[l]) == key_w[cm](w_row[cm](0, l & 15)) for l in range(64))
+                b = [rows[l] * 128 + (((4 * ks + (l >> 4)) ^ key_w[cm](rows[l])) << 4) for l in range(64)]
+                assert conflicts_b128(b)[0] == 1
+    # every column of a wave's 64 is owned exactly once, and the phased kernel's W half b holds the rows of j in {2b, 2b+1}
+    for cm in (1, 2):
+        assert sorted(w_row[cm](j, i) for j in range(4) for i in range(16)) == list(range(64))
         for j in range(4):
-            rows = [_perm_row(l & 15, j) for l in range(64)]
-            b = [rows[l] * 128 + (((4 * ks + (l >> 4)) ^ key_b(rows[l])) << 4) for l in range(64)]
-            assert conflicts_b128(b)[0] == 1
+            assert all((w_row[cm](j, i) >> 5) == (j >> 1) for i in range(16))
+        col4 = (lambda j, h: 16 * j + 4 * h) if cm == 1 else (lambda j, h: 32 * (j >> 1) + 8 * h + 4 * (j & 1))
+        for j in range(4):
+            for h in range(4):
+                # accumulator register r of a lane in quarter h = MFMA row 4h + r of block j
+                assert [w_row[cm](j, 4 * h + r) for r in range(4)] == [col4(j, h) + r for r in range(4)]
 
 
 def test_fused_ffn_weight_reads_are_conflict_free():
