@@ -25,6 +25,20 @@
 #ifndef CCX_GEMM_SETPRIO
 #define CCX_GEMM_SETPRIO 1
 #endif
+// diagnostic builds of the phased kernel (tools/README.md): -DCCX_ABL_NO_MFMA=1 / _NO_DMA (in-loop prefetches) / _NO_EPI /
+// _STORE_LOCAL (every tile stores to the first 256 output rows: the epilogue's instructions without its HBM traffic)
+#ifndef CCX_ABL_NO_MFMA
+#define CCX_ABL_NO_MFMA 0
+#endif
+#ifndef CCX_ABL_NO_DMA
+#define CCX_ABL_NO_DMA 0
+#endif
+#ifndef CCX_ABL_NO_EPI
+#define CCX_ABL_NO_EPI 0
+#endif
+#ifndef CCX_ABL_STORE_LOCAL
+#define CCX_ABL_STORE_LOCAL 0
+#endif
 #define BM 128
 #define BN 128
 #define BK 64
@@ -152,8 +166,9 @@ __device__ __forceinline__ long remap_row(const GemmParams& p, int m, bool& vali
 template <int EPI, int WM, int WN, int MT, typename MainLoop>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, MainLoop mainloop) {
   constexpr int CM = colmap_of(EPI);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave / WN, wc = wave % WN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: column block, head and the q / k / v
+  const int wr = wave / WN, wc = wave % WN;                            // destination pointer stay in SGPRs (no pointer select through memory)
   const int l15 = lane & 15, h = lane >> 4;
   const int cb = n0 + wc * 64;                    // first column of the wave's 64
 
@@ -168,11 +183,18 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     if (blk == 2 && p.v_transposed) {
       mainloop(p, smem, m0, n0, acc, std::false_type{});
       // lane: column n = cb + w_row(j, l15) ; rows m0 + wr*MT*16 + mt*16 + 4h + reg
+      // (the four bias values are loaded AND consumed before the first store: a load waited for inside the row branches costs a
+      // vmcnt(0) per branch, i.e. every store waits for the one before it)
+      float bvj[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) bvj[j] = p.bias ? p.bias[cb + w_row<CM>(j, l15)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) asm volatile("" ::"v"(bvj[j]));
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int n = cb + w_row<CM>(j, l15);
         const int nn = n % p.d_model, hh = nn >> 6, d = nn & 63;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+        const float bv = bvj[j];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
           const int m = m0 + wr * MT * 16 + mt * 16 + 4 * h;
@@ -248,25 +270,44 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
         long orow = m;
         if (!FULL) { orow = 0; if (m < p.M) orow = remap_row(p, m, valid); }
         G.ok[g] = valid; G.orow[g] = orow;
+        // Residual rows are requested WITHOUT a branch around the loads (rows and column groups that will not be stored read row 0 /
+        // column 0 of the residual instead and their sums are dropped): hipcc waits with vmcnt(0) for a load that was issued
+        // under a lane mask as soon as its use sits in another masked block, and with stores in between every store then
+        // waited for the one before it (the ResNet convolutions run this path for every tile: their rows are remapped).
         if constexpr (RES_F32) {
-          const bool has = valid && (EPI != EPI_BF16_LRELU_AFFINE || p.resid != nullptr);
-          const long rrow = (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
+          const bool have = EPI != EPI_BF16_LRELU_AFFINE || p.resid != nullptr;     // block-uniform
+          const long rrow = !valid ? 0 : (EPI != EPI_BF16_LRELU_AFFINE && p.resid_mod > 0) ? (orow % p.resid_mod) : orow;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if (has && (FULL || c4[j] < Nw)) G.rf[g][j] = *(const float4*)(p.resid + rrow * p.ldr + c4[j]);
+            const int cj = (FULL || c4[j] < Nw) ? c4[j] : 0;
+            if (have) G.rf[g][j] = *(const float4*)(p.resid + rrow * p.ldr + cj);
             else G.rf[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
         if constexpr (RES_BF16) {
+          const long rrow = valid ? orow : 0;
 #pragma unroll
           for (int i = 0; i < 2; i++) {
-            if (valid && p.resid_bf16 && (FULL || c4[2 * i] < Nw)) G.rb[g][i] = *(const uint4*)(p.resid_bf16 + orow * p.ldrb + c4[2 * i]);
+            const int ci = (FULL || c4[2 * i] < Nw) ? c4[2 * i] : 0;
+            if (p.resid_bf16) G.rb[g][i] = *(const uint4*)(p.resid_bf16 + rrow * p.ldrb + ci);
             else G.rb[g][i] = make_uint4(0, 0, 0, 0);
           }
         }
       }
     };
     auto finish = [&](int mt0, const Group& G) {
+      // the group's residual is waited for HERE, once and outside the row branches (see request())
+#pragma unroll
+      for (int g = 0; g < GM; g++) {
+        if constexpr (RES_F32) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) asm volatile("" ::"v"(G.rf[g][j].x), "v"(G.rf[g][j].y), "v"(G.rf[g][j].z), "v"(G.rf[g][j].w));
+        }
+        if constexpr (RES_BF16) {
+#pragma unroll
+          for (int i = 0; i < 2; i++) asm volatile("" ::"v"(G.rb[g][i].x), "v"(G.rb[g][i].y), "v"(G.rb[g][i].z), "v"(G.rb[g][i].w));
+        }
+      }
 #pragma unroll
       for (int g = 0; g < GM; g++) {
         const int mt = mt0 + g;
@@ -296,7 +337,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
         }
 
         if (!FULL && !G.ok[g]) continue;
-        const long orow = G.orow[g];
+        const long orow = CCX_ABL_STORE_LOCAL ? (G.orow[g] & 255) : G.orow[g];
 
         if constexpr (EPI == EPI_BF16_LRELU_AFFINE) {
 #pragma unroll
@@ -370,6 +411,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       finish(g0 * GM, G[g0 & 1]);
     }
   };
+  if (CCX_ABL_NO_EPI) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[mt][j]));
+    return;
+  }
   const bool full = p.rpb_in <= 0 && m0 + WM * MT * 16 <= p.M && n0 + WN * 64 <= p.N;
   if (full) rows(std::true_type{});
   else rows(std::false_type{});
@@ -494,7 +542,8 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
   _Pragma("unroll") for (int ks = 0; ks < 2; ks++)                                                          \
   _Pragma("unroll") for (int m = 0; m < 4; m++)                                                             \
   _Pragma("unroll") for (int jj = 0; jj < 2; jj++) {                                                        \
-    if (SWAP) acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[jj][ks], fa[m][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
+    if (CCX_ABL_NO_MFMA) { asm volatile("" ::"v"(FB[jj][ks]), "v"(fa[m][ks])); }                           \
+    else if (SWAP) acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[jj][ks], fa[m][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
     else      acc[MT0 + m][J0 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][ks], FB[jj][ks], acc[MT0 + m][J0 + jj], 0, 0, 0); \
   }                                                                                                         \
   if (CCX_GEMM_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
@@ -513,24 +562,24 @@ __device__ __forceinline__ void gemm_mainloop_phased(const GemmParams& p, char* 
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
       for (int m = 0; m < 4; m++) fa[m][ks] = *(const bf16x8*)(buf + offA[ks] + m * 16 * 128);
-    if (t + 1 < nt) stage_a(t + 1, ka1, 1);
+    if (!CCX_ABL_NO_DMA && t + 1 < nt) stage_a(t + 1, ka1, 1);
     CCX_PHASE_MFMA(0, 0, fb0)
     // phase 2: W1 fragments; prefetch A0(t+2)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
       for (int jj = 0; jj < 2; jj++) fb1[jj][ks] = *(const bf16x8*)(buf + offB[ks] + w_row<CM>(2 + jj, 0) * 128);
-    if (t + 2 < nt) stage_a(t + 2, ka2, 0);
+    if (!CCX_ABL_NO_DMA && t + 2 < nt) stage_a(t + 2, ka2, 0);
     CCX_PHASE_MFMA(0, 2, fb1)
     // phase 3: A1 fragments; prefetch W0(t+2)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
       for (int m = 0; m < 4; m++) fa[m][ks] = *(const bf16x8*)(buf + offA[ks] + (4 + m) * 16 * 128);
-    if (t + 2 < nt) stage_b(t + 2, 0);
+    if (!CCX_ABL_NO_DMA && t + 2 < nt) stage_b(t + 2, 0);
     CCX_PHASE_MFMA(4, 2, fb1)
     // phase 4: W0 fragments are still in registers; prefetch W1(t+2); tile t+1 must have landed before phase 1 of t+1
-    if (t + 2 < nt) {
+    if (!CCX_ABL_NO_DMA && t + 2 < nt) {
       stage_b(t + 2, 1);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
