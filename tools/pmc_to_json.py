@@ -40,6 +40,10 @@ for name, v in out.items():
     if "<" in name:
         b = base[name.split("<")[0]]
         b[0] += v["launches"]; b[1] += v["FETCH_SIZE_kb_per_launch"] * v["launches"]; b[2] += v["WRITE_SIZE_kb_per_launch"] * v["launches"]
+# the GEMM family is ONE label in bench.py ("gemm_bf16_nt_kernel"): the two-stage and the phased tile kernels together
+if "gemm_bf16_phased_kernel" in base:
+    a, b = base["gemm_bf16_nt_kernel"], base["gemm_bf16_phased_kernel"]
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]
 for name, (n, fk, wk) in base.items():
     if name not in out:
         out[name] = {"launches": n, "FETCH_SIZE_kb_per_launch": fk / n, "WRITE_SIZE_kb_per_launch": wk / n,
