@@ -770,20 +770,22 @@ __global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) 
     }
     sm = mn;
   };
-  // q is consumed once here so that hipcc waits for it BEFORE the loop (a wait for q inside the loop would drain the
-  // K/V requests that are younger than it)
-  {
-    float qs = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) qs += q[j];
-    asm volatile("" ::"v"(qs));
-  }
   {
     // no branch around a request or a reduce: one code path, exact load counts.  Pieces past the end of the wave's range
     // re-read its last key row (one cache line) and are masked to -inf scores.  sched_barrier pins the order
     // request(i+1) -> reduce(i): at most two pieces (16 KB) and at least one (8 KB) in flight per wave.
     bf16x8 kA[4], vA[4], kB[4], vB[4];
     load(kA, vA, w0);
+    // q is consumed once HERE: behind the first piece's requests, so that its round trip and theirs overlap (the wait is a
+    // counted vmcnt(8): q is older than the piece), and before the loop (a wait for q inside it would sit on every iteration)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      float qs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) qs += q[j];
+      asm volatile("" ::"v"(qs));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NP; i += 2) {
       const int base = w0 + 32 * i;
