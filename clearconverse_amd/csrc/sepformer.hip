@@ -276,6 +276,184 @@ typedef __attribute__((address_space(3))) void* ff_lptr_t;
 __device__ __forceinline__ int ff_key1(int r) { return (r & 3) | (((r >> 4) & 3) << 2); }          // 256-byte rows
 __device__ __forceinline__ int ff_key2(int r) { return ((r >> 1) & 1) | (((r >> 5) & 1) << 2); }   // 128-byte rows (chunk = 2 hq + s)
 
+// ---------------------------------------------------------------------------------------------
+// Attention half of a transformer layer in ONE kernel for sequences of at most 160 tokens (every intra-chunk call: 150):
+//   h += out_proj(attention(LayerNorm1(h) Wqkv^T + bqkv)) + bo
+// Through separate kernels this half moves 650 MB per call over HBM (LayerNorm output, q|k|v, attention output, the residual
+// twice); here a block (one sequence, 8 waves = 8 heads) reads its 150 x 128 residual rows once and writes them once.
+//   1. LayerNorm of the rows -> bf16 in LDS (40 KB, 16-byte chunks XOR-swizzled by the row so that the fragment reads of 16
+//      consecutive rows are conflict-free).
+//   2. wave w = head w: q^T, k^T = W[16 w ..] x^T and v = x W^T with v_mfma_f32_16x16x32_bf16, weight fragments straight from
+//      global memory into registers (48 rows x 128: 12 fragments).  The operand ORDER is chosen so that the accumulators already
+//      are the operand layouts of the attention MFMAs: q^T / k^T tiles have the token on the lane (B / A operand of S^T = K Q^T),
+//      the v tile has the head dimension on the lane (B operand of O = P V) -- q, k and v never leave registers.
+//   3. attention as in sep_attention_kernel (K and V of all 160 keys resident), O tiles -> bf16 into the same LDS rows.
+//   4. wave w = output columns 16 w ..: out-proj with the Wo fragments from global memory, C^T orientation (lane = token, four
+//      consecutive columns), residual add, float4 store.
+// ---------------------------------------------------------------------------------------------
+constexpr int AB_MAX_TOK = 160;
+__device__ __forceinline__ int ab_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }   // 16 chunks of 16 B per row
+
+__global__ __launch_bounds__(512) void sep_attn_block_kernel(float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                             const bf16_t* __restrict__ Wqkv, const float* __restrict__ bqkv,
+                                                             const bf16_t* __restrict__ Wo, const float* __restrict__ bo,
+                                                             const int* __restrict__ seq_start, const int* __restrict__ seq_len,
+                                                             float scale_log2e, float eps) {
+  __shared__ __attribute__((aligned(16))) char xs[AB_MAX_TOK * 256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, h4 = lane >> 4;
+  const int seq = blockIdx.x;
+  const int s0 = seq_start[seq], len = seq_len[seq];
+  const int n_t = (len + 15) >> 4;                       // token tiles (<= 10)
+
+  // ---- 1. LayerNorm: wave w normalises rows w, w + 8, ...; a lane holds features 2 lane, 2 lane + 1 (ten rows at a time:
+  //         keeps the live registers of this phase low) ----
+  {
+    const float2 g = ((const float2*)ln_g)[lane], b = ((const float2*)ln_b)[lane];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      float2 v[10];
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        const int r = wave + 8 * (10 * half + i);
+        v[i] = r < len ? ((const float2*)(h + (long)(s0 + r) * 128))[lane] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 10; i++) {
+        const int r = wave + 8 * (10 * half + i);
+        const float mean = wave_reduce_sum(v[i].x + v[i].y) * (1.f / 128.f);
+        const float dx = v[i].x - mean, dy = v[i].y - mean;
+        const float rstd = rsqrtf(wave_reduce_sum(dx * dx + dy * dy) * (1.f / 128.f) + eps);
+        uint32_t o = pack_bf16x2(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y);
+        if (r >= len) o = 0;                             // rows past the sequence: zeros (their keys are masked, their queries dropped)
+        *(uint32_t*)(xs + ab_off(r, lane >> 2) + (lane & 3) * 4) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. q^T, k^T, then v of head `wave` for every token tile (two passes over the rows: 32 + 16 weight registers at a time) ----
+  bf16x4v q_all[10], k_all[10], v_all[10];
+  {
+    bf16x8 wq[4], wk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const long o = (long)(16 * wave + l15) * 128 + 32 * ks + 8 * h4;
+      wq[ks] = *(const bf16x8*)(Wqkv + o);
+      wk[ks] = *(const bf16x8*)(Wqkv + 128 * 128 + o);
+    }
+    const float4 bq = *(const float4*)(bqkv + 16 * wave + 4 * h4);
+    const float4 bk = *(const float4*)(bqkv + 128 + 16 * wave + 4 * h4);
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+      const int tt = t < n_t ? t : n_t - 1;              // tiles past the sequence repeat the last one (never used)
+      f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 xf = *(const bf16x8*)(xs + ab_off(16 * tt + l15, 4 * ks + h4));
+        aq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks], xf, aq, 0, 0, 0);   // D[d][token]: lane = token, reg r = d 4 h4 + r
+        ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk[ks], xf, ak, 0, 0, 0);
+      }
+      union { bf16x4v v; uint32_t u[2]; } c;
+      c.u[0] = pack_bf16x2(aq[0] + bq.x, aq[1] + bq.y); c.u[1] = pack_bf16x2(aq[2] + bq.z, aq[3] + bq.w);
+      q_all[t] = c.v;
+      c.u[0] = pack_bf16x2(ak[0] + bk.x, ak[1] + bk.y); c.u[1] = pack_bf16x2(ak[2] + bk.z, ak[3] + bk.w);
+      k_all[t] = c.v;
+    }
+  }
+  {
+    bf16x8 wv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wv[ks] = *(const bf16x8*)(Wqkv + 256 * 128 + (long)(16 * wave + l15) * 128 + 32 * ks + 8 * h4);
+    const float bv = bqkv[256 + 16 * wave + l15];
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+      const int tt = t < n_t ? t : n_t - 1;
+      f32x4 av = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 xf = *(const bf16x8*)(xs + ab_off(16 * tt + l15, 4 * ks + h4));
+        av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wv[ks], av, 0, 0, 0);   // D[token][d]: lane = d, reg r = token 4 h4 + r
+      }
+      union { bf16x4v v; uint32_t u[2]; } c;
+      c.u[0] = pack_bf16x2(av[0] + bv, av[1] + bv); c.u[1] = pack_bf16x2(av[2] + bv, av[3] + bv);
+      v_all[t] = c.v;
+    }
+  }
+  __syncthreads();                                        // every wave is done with the normalised rows: the LDS rows take the O tiles now
+
+  // ---- 3. attention of head `wave` (all keys resident; keys past `len` can only sit in the last key tile) ----
+  for (int qt = 0; qt < n_t; qt++) {
+    bf16x4v qf = q_all[0];
+#pragma unroll
+    for (int t = 1; t < 10; t++) qf = (t == qt) ? q_all[t] : qf;    // uniform select: q_all stays in registers
+    f32x4 sc[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) sc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k_all[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    // sc[t][r] = score(query l15, key 16 t + 4 h4 + r)
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+      if (t * 16 + 16 > len) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (t * 16 + 4 * h4 + r >= len) sc[t][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[t][r]);
+    }
+    mx = fmaxf(mx, lane_xor16(mx));
+    mx = fmaxf(mx, lane_xor32(mx));
+    mx *= scale_log2e;
+    float ps = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};                       // O tile: col = d (l15), rows = query 4 h4 + r
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[t][r], scale_log2e, -mx));
+        sc[t][r] = pv;
+        ps += pv;
+      }
+      union { bf16x4v v; uint32_t u[2]; } pa;              // A operand: P[query l15][key 4 h4 + j]
+      pa.u[0] = pack_bf16x2(sc[t][0], sc[t][1]);
+      pa.u[1] = pack_bf16x2(sc[t][2], sc[t][3]);
+      o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa.v, v_all[t], o, 0, 0, 0);
+    }
+    float lt = ps + lane_xor16(ps);
+    lt += lane_xor32(lt);
+    // rows of the O tile are queries 4 h4 + r: fetch their normalisers; column 16 wave + l15 of the attention output
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = qt * 16 + 4 * h4 + r;
+      const float inv = 1.0f / __shfl(lt, 4 * h4 + r, 64);
+      *(bf16_t*)(xs + ab_off(row, 2 * wave + (l15 >> 3)) + (l15 & 7) * 2) = f32_to_bf16(o[r] * inv);
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. out-proj of columns 16 wave .. + 15, residual add ----
+  {
+    bf16x8 wo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) wo[ks] = *(const bf16x8*)(Wo + (long)(16 * wave + l15) * 128 + 32 * ks + 8 * h4);
+    const float4 b4 = *(const float4*)(bo + 16 * wave + 4 * h4);
+    for (int t = 0; t < n_t; t++) {
+      const int tok = 16 * t + l15;
+      float4* hp = (float4*)(h + (long)(s0 + (tok < len ? tok : len - 1)) * 128 + 16 * wave + 4 * h4);
+      const float4 res = *hp;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const bf16x8 af = *(const bf16x8*)(xs + ab_off(tok, 4 * ks + h4));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[ks], af, acc, 0, 0, 0);    // D[col][token]: lane = token, reg r = col 4 h4 + r
+      }
+      if (tok < len) *hp = make_float4(res.x + acc[0] + b4.x, res.y + acc[1] + b4.y, res.z + acc[2] + b4.z, res.w + acc[3] + b4.w);
+    }
+  }
+}
+
 __global__ __launch_bounds__(512) void sep_ffn_kernel(float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                       const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                       const bf16_t* __restrict__ W2, const float* __restrict__ b2, int n_tok, int d_ffn,
@@ -622,16 +800,29 @@ int load_block(ccx_sepformer* s, const std::string& prefix, SepBlock& B) {
 }
 
 // One SBTransformerBlock_wnormandskip over `n_tok` tokens organised in `n_seq` sequences.
+// `max_len`: the longest sequence of the call (host side); up to 160 tokens the attention half of a layer is one kernel.
 int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* hc, const int* tok_seq, const int* tok_pos,
-              const int* seq_start, const int* seq_len, int n_tok, int n_seq, float* xin, float* h, float* y, hipStream_t st) {
+              const int* seq_start, const int* seq_len, int n_tok, int n_seq, int max_len, float* xin, float* h, float* y, hipStream_t st) {
   ccx_ctx* ctx = s->ctx;
   const int D = s->d.d_model, F = s->d.d_ffn;
   hipLaunchKernelGGL(sep_block_input_kernel, dim3(ccx_cdiv(n_tok * 32, 256)), dim3(256), 0, st, x, hc, tok_seq, tok_pos, s->pe,
                      xin, h, n_tok);
   CCX_CHECK_LAUNCH(ctx);
   const float scale_log2e = 0.25f * 1.4426950408889634f;  // 1/sqrt(16)
+  const char* fenv = getenv("CCX_SEP_FUSED_ATTN");          // read per call: tests compare the two paths in one process
+  const bool fused = (fenv ? atoi(fenv) != 0 : true) && max_len <= AB_MAX_TOK;
   for (const SepLayer& L : B.layers) {
     GemmParams p;
+    if (fused) {
+      {
+        // algorithmic work: QKV + out-proj GEMMs and the two attention products; bytes: the residual rows read and written once
+        ccx_prof_scope ps(ctx, st, "sep_attn_block_kernel", 2.0 * n_tok * (double)D * 4 * D + 4.0 * n_tok * (double)max_len * D,
+                          2.0 * n_tok * D * 4.0 + 2.0 * 4 * D * D);
+        hipLaunchKernelGGL(sep_attn_block_kernel, dim3(n_seq), dim3(512), 0, st, h, L.ln1_g, L.ln1_b, L.Wqkv, L.bqkv, L.Wo, L.bo, seq_start,
+                           seq_len, scale_log2e, 1e-6f);
+      }
+      CCX_CHECK_LAUNCH(ctx);
+    } else {
     STRY(ccx_launch_layernorm(ctx, h, D, L.ln1_g, L.ln1_b, s->xn, nullptr, D, n_tok, D, 1e-6f, st));
     memset(&p, 0, sizeof(p));
     p.A = s->xn; p.lda = D; p.W = L.Wqkv; p.ldw = D; p.M = n_tok; p.N = 3 * D; p.K = D; p.bias = L.bqkv; p.out = s->qkv; p.ldo = 3 * D;
@@ -645,6 +836,7 @@ int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* 
     memset(&p, 0, sizeof(p));
     p.A = s->att; p.lda = D; p.W = L.Wo; p.ldw = D; p.M = n_tok; p.N = D; p.K = D; p.bias = L.bo; p.out = h; p.ldo = D; p.resid = h; p.ldr = D;
     STRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, st));
+    }
     {
       // LayerNorm 2 + Linear-ReLU-Linear + residual in one kernel (see sep_ffn_kernel)
       static bool attr_set = false;
@@ -766,7 +958,7 @@ int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, c
   const int D = d.d_model, seg = d.segment;
   // ---- host-side ragged bookkeeping (tiny) ----
   std::vector<int> uL(B), uT(B), utok0(B), uchunk0(B), unchunk(B);
-  int n_tok = 0, n_chunk = 0;
+  int n_tok = 0, n_chunk = 0, max_nchunk = 0;
   for (int b = 0; b < B; b++) {
     CCX_REQUIRE(ctx, n_samples[b] >= d.kernel && n_samples[b] <= stride, "sepformer_separate: utterance %d has %d samples (need >= %d, <= stride)", b, n_samples[b], d.kernel);
     uT[b] = n_samples[b];
@@ -775,6 +967,7 @@ int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, c
     unchunk[b] = (uL[b] + rest) / seg;
     utok0[b] = n_tok; uchunk0[b] = n_chunk;
     n_tok += unchunk[b] * seg; n_chunk += unchunk[b];
+    max_nchunk = unchunk[b] > max_nchunk ? unchunk[b] : max_nchunk;
   }
   CCX_REQUIRE(ctx, n_tok <= s->max_tokens, "sepformer_separate: %d tokens exceed capacity %d", n_tok, s->max_tokens);
   CCX_REQUIRE(ctx, n_chunk <= s->pe_len, "sepformer_separate: memory sequence too long");
@@ -802,14 +995,14 @@ int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, c
   const float* cur = s->feats;
   const float* hc = nullptr;
   for (int i = 0; i < d.n_blocks; i++) {
-    STRY(run_block(s, s->seg[i], cur, hc, s->tok_chunk, s->tok_cpos, s->chunk_start, s->chunk_len, n_tok, n_chunk, s->xin, s->h,
+    STRY(run_block(s, s->seg[i], cur, hc, s->tok_chunk, s->tok_cpos, s->chunk_start, s->chunk_len, n_tok, n_chunk, seg, s->xin, s->h,
                    s->x, st));
     cur = s->x;
     if (i < d.n_blocks - 1) {
       hipLaunchKernelGGL(sep_chunk_mean_kernel, dim3(n_chunk), dim3(128), 0, st, s->x, s->memx, seg);
       CCX_CHECK_LAUNCH(ctx);
       // memory transformer: one sequence per utterance over its chunk means
-      STRY(run_block(s, s->mem[i], s->memx, nullptr, s->mem_utt, s->mem_pos, s->utt_chunk0, s->utt_nchunk, n_chunk, B, s->memxin,
+      STRY(run_block(s, s->mem[i], s->memx, nullptr, s->mem_utt, s->mem_pos, s->utt_chunk0, s->utt_nchunk, n_chunk, B, max_nchunk, s->memxin,
                      s->memh, s->hc, st));
       hc = s->hc;
     }

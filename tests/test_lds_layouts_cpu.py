@@ -69,3 +69,13 @@ def test_lstm_state_rows_are_conflict_free():
     for kk in range(4):
         assert conflicts_b128([(l & 15) * 288 + 64 * kk + 16 * (l >> 4) for l in range(64)])[0] == 1
         assert conflicts_b128([(l & 15) * 272 + 64 * kk + 16 * (l >> 4) for l in range(64)])[0] == 2   # the first pitch tried
+
+
+def test_fused_attention_block_reads_are_conflict_free():
+    # csrc/sepformer.hip sep_attn_block_kernel: 256-byte rows (128 bf16), chunk c of row r stored at chunk c ^ (r & 15);
+    # fragment reads: lane (l15, h4) reads row 16 t + l15, chunk 4 ks + h4
+    off = lambda row, chunk: row * 256 + ((chunk ^ (row & 15)) << 4)
+    for t in range(10):
+        for ks in range(4):
+            a = [off(16 * t + (l & 15), 4 * ks + (l >> 4)) for l in range(64)]
+            assert conflicts_b128(a)[0] == 1

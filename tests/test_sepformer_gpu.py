@@ -121,3 +121,38 @@ def test_fused_ffn_other_widths(ccx_ctx, d_ffn):
             assert _rel(got[i, :n], ref) < 3e-2, (i, _rel(got[i, :n], ref))
     finally:
         m.close()
+
+
+def test_fused_attention_block_matches_the_separate_kernels(small, monkeypatch):
+    """Sequences of up to 160 tokens run the attention half of a layer as ONE kernel (sep_attn_block_kernel); longer ones
+    (memory sequences of utterances above ~24 s) go through LayerNorm / QKV GEMM / sep_attention_kernel / out-proj GEMM.
+    Same math, different summation orders and one bf16 rounding less: the separated waveforms agree to 1e-2 of their norm,
+    and both stay within the oracle tolerance."""
+    dims, sd, m = small
+    lengths = [8000, 5213, 1216]
+    mix = _mix(lengths, seed=3)
+    fused = m.separate_batch(mix, lengths).cpu()
+    monkeypatch.setenv("CCX_SEP_FUSED_ATTN", "0")
+    split = m.separate_batch(mix, lengths).cpu()
+    monkeypatch.delenv("CCX_SEP_FUSED_ATTN")
+    assert not torch.equal(fused, split)          # the switch did select another path
+    orc = S.SepformerRef(S.SepDims(**dims.__dict__), sd)
+    for i, n in enumerate(lengths):
+        assert _rel(fused[i, :n], split[i, :n]) < 1e-2, (i, _rel(fused[i, :n], split[i, :n]))
+        ref = orc.separate(mix[i:i + 1, :n])[0]
+        assert _rel(split[i, :n], ref) < 3e-2 and _rel(fused[i, :n], ref) < 3e-2
+
+
+def test_long_utterance_takes_the_separate_kernels(ccx_ctx):
+    """An utterance of 26 s has 174 chunks: its memory sequences exceed the fused kernel's 160 tokens, its chunks do not."""
+    from clearconverse_amd.separator import SepformerSeparator
+    dims = SepDims(n_layers=1)
+    sd = synthetic_sepformer_state_dict(dims, seed=6)
+    m = SepformerSeparator(dims, sd, max_tokens=30000, max_utts=2, ctx=ccx_ctx)
+    n = 26 * 8000
+    mix = _mix([n], seed=5)
+    got = m.separate_batch(mix, [n]).cpu()
+    ref = S.SepformerRef(S.SepDims(**dims.__dict__), sd).separate(mix[:, :n])[0]
+    m.close()
+    assert torch.isfinite(got).all()
+    assert _rel(got[0, :n], ref) < 3e-2, _rel(got[0, :n], ref)
