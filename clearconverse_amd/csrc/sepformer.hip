@@ -654,36 +654,57 @@ __global__ void sep_prelu_bf16_kernel(const float* __restrict__ x, const float* 
 // ---------------------------------------------------------------------------------------------
 // Mask (ReLU) * encoder output, ConvTranspose1d(128 -> 1, k16, s8) overlap-add, pad/trim to T:
 //   est[u][t][spk] = sum_{l in {t/8, t/8-1}} sum_c feats[l][c] * relu(fc[l][2c+spk]) * wdec[c][t-8l]
-// One wave per output sample pair-of-speakers: lanes split the 128 channels.
+// One wave per group of 8 output samples t = 8 l .. 8 l + 7 (both speakers): they all need exactly the token rows l (taps 0..7)
+// and l - 1 (taps 8..15), which are read ONCE per wave -- with a wave per sample every 1.5 KB token row came out of L2
+// sixteen times (18 GB per pipeline step, the whole 5.2 ms of the kernel).  Lanes split the 128 channels.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sep_decoder_kernel(const float* __restrict__ feats, const float* __restrict__ fc,
                                                           const int* __restrict__ utt_tok0, const int* __restrict__ utt_L,
                                                           const int* __restrict__ utt_T, const float* __restrict__ wdec,  // [128][16]
                                                           float* __restrict__ out, long out_stride, int n_utt) {
   const int u = blockIdx.y;
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // sample group: t = 8 l + k
   const int T = utt_T[u], L = utt_L[u];
-  if (t >= out_stride) return;
-  if (t >= T) {  // rows past the utterance are zero (separate_batch pads / trims to T)
-    if (lane == 0) ((float2*)(out + ((long)u * out_stride + t) * 2))[0] = make_float2(0.f, 0.f);
+  const long t0 = 8L * l;
+  if (t0 >= out_stride) return;
+  float2* dst = (float2*)(out + ((long)u * out_stride + t0) * 2);
+  if (t0 >= T || l > L) {  // rows past the utterance are zero (separate_batch pads / trims to T)
+    if (lane < 8 && t0 + lane < out_stride) dst[lane] = make_float2(0.f, 0.f);
     return;
   }
-  float a0 = 0.f, a1 = 0.f;
-  const int l_hi = t >> 3;
+  // g[token][spk][channel of the lane]: feats * relu(mask); token 0 = l (taps k), token 1 = l - 1 (taps k + 8)
+  float g[2][2][2];
 #pragma unroll
   for (int dl = 0; dl < 2; dl++) {
-    const int l = l_hi - dl, k = t - 8 * l;
-    if (l < 0 || l >= L || k >= 16) continue;
-    const long tok = utt_tok0[u] + l;
+    const int ll = l - dl;
+    const bool ok = ll >= 0 && ll < L;
+    const long tok = utt_tok0[u] + (ok ? ll : 0);
     const float2 f = ((const float2*)(feats + tok * 128))[lane];          // channels 2*lane, 2*lane+1
     const float4 m = ((const float4*)(fc + tok * 256))[lane];             // (c0,s0) (c0,s1) (c1,s0) (c1,s1)
-    const float w0 = wdec[(2 * lane) * 16 + k], w1 = wdec[(2 * lane + 1) * 16 + k];
-    a0 += f.x * fmaxf(m.x, 0.f) * w0 + f.y * fmaxf(m.z, 0.f) * w1;
-    a1 += f.x * fmaxf(m.y, 0.f) * w0 + f.y * fmaxf(m.w, 0.f) * w1;
+    const float z = ok ? 1.f : 0.f;
+    g[dl][0][0] = z * f.x * fmaxf(m.x, 0.f); g[dl][0][1] = z * f.y * fmaxf(m.z, 0.f);
+    g[dl][1][0] = z * f.x * fmaxf(m.y, 0.f); g[dl][1][1] = z * f.y * fmaxf(m.w, 0.f);
   }
-  a0 = wave_reduce_sum(a0);
-  a1 = wave_reduce_sum(a1);
-  if (lane == 0) ((float2*)(out + ((long)u * out_stride + t) * 2))[0] = make_float2(a0, a1);
+  float4 w0[4], w1[4];                                                    // wdec rows of channels 2 lane, 2 lane + 1: 16 taps each
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    w0[i] = ((const float4*)(wdec + (2 * lane) * 16))[i];
+    w1[i] = ((const float4*)(wdec + (2 * lane + 1) * 16))[i];
+  }
+  const float* w0f = (const float*)w0;
+  const float* w1f = (const float*)w1;
+  float2 res = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float a0 = g[0][0][0] * w0f[k] + g[0][0][1] * w1f[k];
+    float a1 = g[0][1][0] * w0f[k] + g[0][1][1] * w1f[k];
+    a0 += g[1][0][0] * w0f[k + 8] + g[1][0][1] * w1f[k + 8];
+    a1 += g[1][1][0] * w0f[k + 8] + g[1][1][1] * w1f[k + 8];
+    a0 = wave_reduce_sum(a0);
+    a1 = wave_reduce_sum(a1);
+    if (lane == k) res = make_float2(a0, a1);
+  }
+  if (lane < 8 && t0 + lane < out_stride) dst[lane] = (t0 + lane < T) ? res : make_float2(0.f, 0.f);
 }
 
 struct HostT {
@@ -1013,7 +1034,7 @@ int ccx_sepformer_separate(ccx_sepformer* s, const float* mix, int64_t stride, c
   memset(&p, 0, sizeof(p));
   p.A = s->xn; p.lda = D; p.W = s->W_fc; p.ldw = D; p.M = n_tok; p.N = 2 * D; p.K = D; p.bias = s->b_fc; p.out = s->fc; p.ldo = 2 * D;
   STRY(ccx_launch_gemm(ctx, EPI_F32, p, st));
-  hipLaunchKernelGGL(sep_decoder_kernel, dim3(ccx_cdiv((int)stride, 4), B), dim3(256), 0, st, s->feats, s->fc, s->utt_tok0, s->utt_L,
+  hipLaunchKernelGGL(sep_decoder_kernel, dim3(ccx_cdiv(ccx_cdiv((int)stride, 8), 4), B), dim3(256), 0, st, s->feats, s->fc, s->utt_tok0, s->utt_L,
                      s->utt_T, s->w_dec, out, (long)stride, B);
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
