@@ -123,17 +123,17 @@ def main():
     os.environ.setdefault("CCX_PROF_SHAPES", "1")      # per-shape GEMM labels in the profiled step (folded back below)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: three 2-batch decode groups timed behind one warm-up group -- a single group (--steps 2) has no earlier decode
-    # for its front end to overlap with and reads ~5 % slower than the steady state the driver's --steps 20 --warmup 5 shows
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: two 4-batch decode groups timed behind one warm-up group -- a single group has no earlier decode for its front
+    # end to overlap with and reads ~5 % slower than the steady state the driver's --steps 20 --warmup 5 shows
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", choices=("pipeline", "whisper"), default="pipeline")
     ap.add_argument("--batch", type=int, default=None, help="30 s clips per GPU per step (default 32 pipeline / 8 whisper)")
     ap.add_argument("--sample-len", type=int, default=224)
     ap.add_argument("--whisper-group", type=int, default=192, help="sequences decoded together in the pipeline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="one extra (untimed) step with a sync after every stage")
-    ap.add_argument("--decode-span", type=int, default=2,
+    ap.add_argument("--decode-span", type=int, default=4,
                     help="pipelined schedule: batches whose Whisper windows are encoded and decoded together (1 = one decode group per batch)")
     ap.add_argument("--schedule", choices=("pipelined", "sequential"), default="pipelined",
                     help="pipeline workload: overlap batch i's Whisper decode with batch i+1's front end (default) or run each batch start to finish")
@@ -443,6 +443,7 @@ def main():
             "kernel_ms_per_step": stage_ms,
             "model_load_ms": round(load_ms, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 1),
+            "hbm_used_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

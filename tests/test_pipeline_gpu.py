@@ -83,8 +83,9 @@ def test_pipelined_schedule_equals_sequential(ccx_ctx):
     bp = BatchPipeline(m, whisper_group=8, sample_len=6)            # 12 windows per 2-clip batch -> two groups per batch
     batches = [torch.from_numpy(np.stack([synthetic_clip(10 * k + i, 30.0) for i in range(2)])).cuda() for k in range(3)]
     seq = [bp.run_pinned(a, debug=True) for a in batches]
-    for span in (1, 1, 2, 3):                                       # span 1 twice: the second pass replays captured graphs
-        # span 2: decode units of two batches (24 windows -> 3 groups of 8) + a trailing unit of one batch; span 3: one unit
+    for span in (1, 1, 2, 3, 4):                                    # span 1 twice: the second pass replays captured graphs
+        # span 2: decode units of two batches (24 windows -> 3 groups of 8) + a trailing unit of one batch; span 3: one unit;
+        # span 4 (bench.py's default): more than there are batches -> the same single unit
         pip = bp.run_pinned_pipelined(batches, debug=True, span=span)
         assert len(pip) == len(seq)
         for a, b in zip(seq, pip):
