@@ -120,21 +120,34 @@ __global__ __launch_bounds__(256) void sg_bin_stats_kernel(const float* __restri
   if (live && grp == 0) thresh[clip * SG_LD + b] = mean + n_std * sqrtf(q / (float)nf);
 }
 
-// mask (hard gate scaled by prop_decrease) convolved along bins with the 33-tap triangle
-__global__ void sg_mask_freq_kernel(const float* __restrict__ db, const float* __restrict__ floorv, const float* __restrict__ thresh,
-                                    const int* __restrict__ n_frames, long clip_stride_rows, float prop, const float* __restrict__ ff,
-                                    float* __restrict__ tmp) {
-  const int clip = blockIdx.z, fr = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (fr >= n_frames[clip] || b >= SG_BINS) return;
+// mask (hard gate scaled by prop_decrease) convolved along bins with the 33-tap triangle.  A block of 128 threads = 128 bins of
+// one frame: the 160 mask values it needs (16 bins of halo on either side) are computed once into LDS -- every thread used to
+// recompute the mask of all 33 bins of its window from three global arrays.  Same taps in the same order: bit-identical.
+__global__ __launch_bounds__(128) void sg_mask_freq_kernel(const float* __restrict__ db, const float* __restrict__ floorv,
+                                                           const float* __restrict__ thresh, const int* __restrict__ n_frames,
+                                                           long clip_stride_rows, float prop, const float* __restrict__ ff,
+                                                           float* __restrict__ tmp) {
+  __shared__ float m[160];
+  const int clip = blockIdx.z, fr = blockIdx.y, b0 = blockIdx.x * 128, t = threadIdx.x;
+  if (fr >= n_frames[clip]) return;                      // block-uniform
   const long row = ((long)clip * clip_stride_rows + fr) * SG_LD;
+  for (int i = t; i < 160; i += 128) {
+    const int bb = b0 + i - 16;
+    float v = 0.f;
+    if (bb >= 0 && bb < SG_BINS) {
+      const float d = fmaxf(db[row + bb], floorv[clip * SG_LD + bb]);
+      v = d > thresh[clip * SG_LD + bb] ? 1.0f : 1.0f - prop;
+    }
+    m[i] = v;
+  }
+  __syncthreads();
+  const int b = b0 + t;
+  if (b >= SG_BINS) return;
   float acc = 0.f;
 #pragma unroll
   for (int i = 0; i < 33; i++) {
     const int bb = b + i - 16;
-    if (bb >= 0 && bb < SG_BINS) {
-      const float v = fmaxf(db[row + bb], floorv[clip * SG_LD + bb]);
-      acc += ff[i] * (v > thresh[clip * SG_LD + bb] ? 1.0f : 1.0f - prop);
-    }
+    if (bb >= 0 && bb < SG_BINS) acc += ff[i] * m[t + i];
   }
   tmp[row + b] = acc;
 }
