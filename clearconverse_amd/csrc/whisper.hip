@@ -1083,7 +1083,9 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     const char* e = getenv("CCX_DEC_LANES");
     const int forced = e ? atoi(e) : 0;
     if (forced >= 1) nl = forced;
-    else nl = B >= 144 ? 3 : (B >= 96 ? 2 : 1);   // measured at 192 sequences x 65 steps: 1 lane 292.5, 2 286.8, 3 284.9, 4 284.8 ms
+    // measured at 192 sequences x 65 steps: 1 lane 292.5, 2 286.8, 3 284.9, 4 284.8 ms; pipeline step with 384-sequence groups: 2 lanes
+    // 710.0, 3 lanes 698.0 ms; with 768-sequence groups: 1 lane 721.5, 2 lanes 676.6, 3 lanes 687.5, 4 lanes 704.0 ms
+    else nl = B >= 640 ? 2 : (B >= 144 ? 3 : (B >= 96 ? 2 : 1));
     if (nl > ccx_whisper::kMaxLanes) nl = ccx_whisper::kMaxLanes;
     while (nl > 1 && B / nl < 16) nl--;
   }
