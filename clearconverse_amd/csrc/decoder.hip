@@ -530,6 +530,25 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
   // wide-N layers (logits) use 64-row weight panels per block, narrow ones 16 to spread over more CUs
   const bool wide = p.N >= 8192;
   if (act == ACT_BF16 && epi == DEPI_F32 && wide) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
+  // Lanes of 128 rows and more (the decode groups of the pipelined schedule): a block of 16 output columns re-reads all of its 64
+  // activation rows for 24 KB of weights, so the launch is bound by activation reads out of L2 (85 MB for the 1.2 MB QKV matrix
+  // at 384 rows); 32 columns per block halve that: pipeline step 678.3 -> 653.8 ms with 2 lanes x 384 rows, 698 -> 683 with
+  // 3 x 128 (64 columns per block: 659.9).  CCX_DEC_WIDE_ROWS sets the row count from which it applies (0 = never),
+  // CCX_DEC_WIDE_NT=4 selects 64 columns.
+  static const int wide_rows = [] { const char* e = getenv("CCX_DEC_WIDE_ROWS"); return e ? atoi(e) : 128; }();
+  static const int wide_nt = [] { const char* e = getenv("CCX_DEC_WIDE_NT"); return e ? atoi(e) : 2; }();
+  if (wide_rows > 0 && p.M >= wide_rows && act == ACT_BF16 && wide_nt == 4) {
+    if (epi == DEPI_PARTIAL) return launch_dec_linear_mt<4, ACT_BF16, DEPI_PARTIAL>(ctx, p, ksplit, stream);
+    if (epi == DEPI_F32) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
+    if (epi == DEPI_SELF_QKV) return launch_dec_linear_mt<4, ACT_BF16, DEPI_SELF_QKV>(ctx, p, 1, stream);
+    if (epi == DEPI_BF16_GELU) return launch_dec_linear_mt<4, ACT_BF16, DEPI_BF16_GELU>(ctx, p, 1, stream);
+  }
+  if (wide_rows > 0 && p.M >= wide_rows && act == ACT_BF16) {
+    if (epi == DEPI_PARTIAL) return launch_dec_linear_mt<2, ACT_BF16, DEPI_PARTIAL>(ctx, p, ksplit, stream);
+    if (epi == DEPI_F32) return launch_dec_linear_mt<2, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
+    if (epi == DEPI_SELF_QKV) return launch_dec_linear_mt<2, ACT_BF16, DEPI_SELF_QKV>(ctx, p, 1, stream);
+    if (epi == DEPI_BF16_GELU) return launch_dec_linear_mt<2, ACT_BF16, DEPI_BF16_GELU>(ctx, p, 1, stream);
+  }
   if (act == ACT_LN && epi == DEPI_SELF_QKV) return launch_dec_linear_mt<1, ACT_LN, DEPI_SELF_QKV>(ctx, p, 1, stream);
   if (act == ACT_LN && epi == DEPI_F32) return launch_dec_linear_mt<1, ACT_LN, DEPI_F32>(ctx, p, 1, stream);
   if (act == ACT_LN && epi == DEPI_BF16_GELU) return launch_dec_linear_mt<1, ACT_LN, DEPI_BF16_GELU>(ctx, p, 1, stream);
