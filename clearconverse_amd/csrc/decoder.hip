@@ -537,7 +537,8 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
   // CCX_DEC_WIDE_NT=4 selects 64 columns.
   static const int wide_rows = [] { const char* e = getenv("CCX_DEC_WIDE_ROWS"); return e ? atoi(e) : 128; }();
   static const int wide_nt = [] { const char* e = getenv("CCX_DEC_WIDE_NT"); return e ? atoi(e) : 2; }();
-  if (wide_rows > 0 && p.M >= wide_rows && act == ACT_BF16 && wide_nt == 4) {
+  static const int nt4_min_n = [] { const char* e = getenv("CCX_DEC_NT4_MIN_N"); return e ? atoi(e) : 1 << 30; }();
+  if (wide_rows > 0 && p.M >= wide_rows && act == ACT_BF16 && (wide_nt == 4 || p.N >= nt4_min_n)) {
     if (epi == DEPI_PARTIAL) return launch_dec_linear_mt<4, ACT_BF16, DEPI_PARTIAL>(ctx, p, ksplit, stream);
     if (epi == DEPI_F32) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);
     if (epi == DEPI_SELF_QKV) return launch_dec_linear_mt<4, ACT_BF16, DEPI_SELF_QKV>(ctx, p, 1, stream);
