@@ -233,6 +233,12 @@ def main():
     load_ms = (time.perf_counter() - t_load0) * 1e3
     if pipelined:
         step()                        # one sequential pass first: one-time kernel set-up and graph capture happen unoverlapped
+        # every decode-group shape of the timed region is captured before it: K timed steps form full groups of `span` batches
+        # plus one group of K % span, and a warm-up shorter than a group would leave the full group's graphs to the timed region
+        shapes = {min(args.decode_span, args.steps)} | ({args.steps % args.decode_span} - {0})
+        covered = {min(args.decode_span, args.warmup)} | ({args.warmup % args.decode_span} - {0}) if args.warmup > 0 else set()
+        for n_ in sorted(shapes - covered):
+            run_steps(n_)
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
