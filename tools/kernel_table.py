@@ -1,7 +1,8 @@
+"""One sequential front-end + encoder step of the pipeline workload with libccx's per-launch events on: calls, ms, TFLOP/s and
+TB/s (algorithmic) per instrumented kernel.  Kernels without a prof scope do not show: tools/step_kernel_diff.sh lists those."""
 import os, sys, collections
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))) if "__file__" in globals() else "/root/repo")
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clearconverse_amd import _lib
 from clearconverse_amd.audio import synthetic_clip
 from clearconverse_amd.batch import BatchPipeline
