@@ -103,6 +103,10 @@ def load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise CcxError(f"{LIB_PATH} is missing: run `python -m clearconverse_amd.build` "
                        "(there is no CPU fallback for the HIP path)")
+    # torch first: libccx.so needs libamdhip64, and the process must end up with ONE HIP runtime.  PyTorch's ROCm wheels carry
+    # their own copy; if libccx were loaded before torch, it would bind /opt/rocm's copy and torch would later load a second
+    # runtime -- ccx_ctx_create then reports "no ROCm-capable device" (seen with build() and smoke() in one process).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(str(LIB_PATH))
     except OSError as e:
