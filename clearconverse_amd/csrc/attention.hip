@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256, 2) void enc_attention_kernel(
     const float m_new = fmaxf(m_run, mx * scale_log2e);      // scale > 0: the maximum commutes with it
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
+    // (the row sums through the matrix core instead -- a constant "ones" row tile as a third V^T tile, 4 more MFMAs per key tile,
+    // 32 adds per lane fewer -- were measured: 20.0 -> 22.5 ms per step; an MFMA holds the issue port longer than the adds it saves)
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; kt++)
