@@ -871,6 +871,143 @@ __global__ __launch_bounds__(256) void dec_cross_stream_kernel(DecAttnParams p) 
   }
 }
 
+// Prompt prefill of the cross attention, RB prompt rows per block.  A sequence's prompt rows all attend to ITS K/V: with one block
+// per (sequence, head, row) (dec_cross_stream_kernel<.., PRE>) the 384 KB of a head came out of L2 once per row (35 GB per
+// 768-sequence prefill at 10 rows, ~2 TB/s effective).  Here a block streams the K/V of one (sequence, head) ONCE per RB rows:
+// every 32-key piece is reduced against RB queries.  Same wave / piece structure as the streaming kernel (a wave owns a contiguous
+// quarter of the keys, the next piece is requested before the current one is reduced), cacheable loads, XCD-aware block order.
+template <int NP, int RB>
+__global__ __launch_bounds__(256) void dec_cross_prefill_kernel(DecAttnParams p) {
+  __shared__ float sm_m[RB][4][8], sm_l[RB][4][8], sm_o[RB][4][8][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ngrp = (p.rows_per_seq + RB - 1) / RB;                  // row groups per (sequence, head)
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int L = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+  const int tg = L % ngrp, sh = L / ngrp;
+  const int h = sh % p.H, sq = sh / p.H;
+  const int t0 = tg * RB;
+  const int g = lane >> 3, c = lane & 7;
+  const int T = p.T;
+  const int per_w = ((T + 3) / 4 + 31) & ~31;
+  const int w0 = __builtin_amdgcn_readfirstlane(wave * per_w);
+  const int w1 = __builtin_amdgcn_readfirstlane((w0 + per_w < T) ? w0 + per_w : T);
+  const bf16_t* Kb = p.k + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
+  const bf16_t* Vb = p.v + ((long)sq * p.H + h) * p.kv_T * 64 + 8 * c;
+
+  float q[RB][8], sm[RB], sl[RB], so[RB][8];
+#pragma unroll
+  for (int r = 0; r < RB; r++) {
+    const int t = t0 + r < p.rows_per_seq ? t0 + r : p.rows_per_seq - 1;      // rows past the prompt repeat the last one (not stored)
+    const float4* qp = (const float4*)(p.q + ((long)(sq * p.rows_per_seq + t) * p.H + h) * 64 + 8 * c);
+    const float4 a = qp[0], d = qp[1];
+    q[r][0] = a.x; q[r][1] = a.y; q[r][2] = a.z; q[r][3] = a.w; q[r][4] = d.x; q[r][5] = d.y; q[r][6] = d.z; q[r][7] = d.w;
+    sm[r] = -1e30f; sl[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) so[r][j] = 0.f;
+  }
+  auto load = [&](bf16x8 (&kf)[4], bf16x8 (&vf)[4], int base) {
+    long off[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      int key = base + it * 8 + g;
+      key = key < w1 ? key : T - 1;
+      off[it] = (long)key * 64;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; it++) kf[it] = *(const bf16x8*)(Kb + off[it]);
+#pragma unroll
+    for (int it = 0; it < 4; it++) vf[it] = *(const bf16x8*)(Vb + off[it]);
+  };
+  auto reduce = [&](const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int base) {
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      float s[4];
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) a = fmaf(q[r][j], bf16_to_f32((bf16_t)kf[it][j]), a);
+        a = group8_sum(a) * p.scale_log2e;
+        s[it] = (base + it * 8 + g < w1) ? a : -INFINITY;
+      }
+      float mn = sm[r];
+#pragma unroll
+      for (int it = 0; it < 4; it++) mn = fmaxf(mn, s[it]);
+      const float al = __builtin_amdgcn_exp2f(sm[r] - mn);
+      sl[r] *= al;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[r][j] *= al;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const float pe = __builtin_amdgcn_exp2f(s[it] - mn);
+        sl[r] += pe;
+#pragma unroll
+        for (int j = 0; j < 8; j++) so[r][j] = fmaf(pe, bf16_to_f32((bf16_t)vf[it][j]), so[r][j]);
+      }
+      sm[r] = mn;
+    }
+  };
+  {
+    // a real loop here (the decode-step kernel is straight-line code for exact load counts; this one runs once per decode
+    // and lives within 256 registers only as a loop): the next piece is requested, the current one reduced against RB rows
+    bf16x8 kA[4], vA[4], kB[4], vB[4];
+    load(kA, vA, w0);
+#pragma unroll 1
+    for (int i = 0; i < NP; i++) {
+      const int base = w0 + 32 * i;
+      load(kB, vB, base + 32 < w1 ? base + 32 : base);
+      reduce(kA, vA, base);
+#pragma unroll
+      for (int it = 0; it < 4; it++) { kA[it] = kB[it]; vA[it] = vB[it]; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; r++) {
+    auto merge_with = [&](float om, float ol, const float (&oo)[8]) {
+      const float mx = fmaxf(sm[r], om);
+      const float wa = __builtin_amdgcn_exp2f(sm[r] - mx), wb = __builtin_amdgcn_exp2f(om - mx);
+      sl[r] = sl[r] * wa + ol * wb;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[r][j] = so[r][j] * wa + oo[j] * wb;
+      sm[r] = mx;
+    };
+    float om, ol, oo[8];
+    om = dpp_mov<0x128>(sm[r]); ol = dpp_mov<0x128>(sl[r]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = dpp_mov<0x128>(so[r][j]);
+    merge_with(om, ol, oo);
+    om = lane_xor16(sm[r]); ol = lane_xor16(sl[r]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor16(so[r][j]);
+    merge_with(om, ol, oo);
+    om = lane_xor32(sm[r]); ol = lane_xor32(sl[r]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor32(so[r][j]);
+    merge_with(om, ol, oo);
+    if (g == 0) {
+      sm_m[r][wave][c] = sm[r]; sm_l[r][wave][c] = sl[r];
+#pragma unroll
+      for (int j = 0; j < 8; j++) sm_o[r][wave][c][j] = so[r][j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < RB * 64; e += 256) {
+    const int r = e >> 6, d = e & 63;
+    if (t0 + r >= p.rows_per_seq) continue;
+    const int cc = d >> 3, j = d & 7;
+    const float mx = fmaxf(fmaxf(sm_m[r][0][cc], sm_m[r][1][cc]), fmaxf(sm_m[r][2][cc], sm_m[r][3][cc]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float ww = __builtin_amdgcn_exp2f(sm_m[r][w][cc] - mx);
+      l += ww * sm_l[r][w][cc];
+      o += ww * sm_o[r][w][cc][j];
+    }
+    p.out_bf16[((long)(sq * p.rows_per_seq + t0 + r) * p.H + h) * 64 + d] = f32_to_bf16(o / l);
+  }
+}
+
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out,
                              hipStream_t stream) {
   CCX_REQUIRE(ctx, B > 0 && p.H > 0 && nsplit >= 1, "dec_attention: bad shape");
@@ -889,10 +1026,19 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
     if (p.rows_per_seq > 1 && !p.pos) {
       // prompt prefill: B = sequences here, one block per (sequence, head, prompt row), whole key range per block
       CCX_REQUIRE(ctx, nsplit == 1 && final_out && np_need <= 12, "dec_attention: the prefill cross attention takes the whole key range (T <= 1536)");
-      dim3 pgrid(B * p.H * p.rows_per_seq, 1);
-      if (np_need <= 4) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 4, true>), pgrid, dim3(256), 0, stream, p);
-      else if (np_need <= 6) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 6, true>), pgrid, dim3(256), 0, stream, p);
-      else hipLaunchKernelGGL((dec_cross_stream_kernel<true, 12, true>), pgrid, dim3(256), 0, stream, p);
+      static const int rb_env = [] { const char* e = getenv("CCX_PREFILL_ROWS_PER_BLOCK"); return e ? atoi(e) : 4; }();
+      if (rb_env == 4 && p.rows_per_seq >= 3) {
+        // four prompt rows per block: the K/V of a (sequence, head) comes out of L2 once per four rows
+        dim3 g4(B * p.H * ccx_cdiv(p.rows_per_seq, 4), 1);
+        if (np_need <= 4) hipLaunchKernelGGL((dec_cross_prefill_kernel<4, 4>), g4, dim3(256), 0, stream, p);
+        else if (np_need <= 6) hipLaunchKernelGGL((dec_cross_prefill_kernel<6, 4>), g4, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dec_cross_prefill_kernel<12, 4>), g4, dim3(256), 0, stream, p);
+      } else {
+        dim3 pgrid(B * p.H * p.rows_per_seq, 1);
+        if (np_need <= 4) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 4, true>), pgrid, dim3(256), 0, stream, p);
+        else if (np_need <= 6) hipLaunchKernelGGL((dec_cross_stream_kernel<true, 6, true>), pgrid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((dec_cross_stream_kernel<true, 12, true>), pgrid, dim3(256), 0, stream, p);
+      }
     } else if (p.stream_mode && !p.pos && np_need <= 12) {
       const int pad = p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0;
 #define CCX_CROSS_STREAM_LAUNCH(F, ...)                                                                                      \
