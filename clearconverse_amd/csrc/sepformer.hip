@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512) void sep_attn_block_kernel(float* __restrict__
   const int l15 = lane & 15, h4 = lane >> 4;
   const int seq = blockIdx.x;
   const int s0 = seq_start[seq], len = seq_len[seq];
+  if (len <= 0) return;                                  // (block-uniform; the host never passes an empty sequence)
   const int n_t = (len + 15) >> 4;                       // token tiles (<= 10)
 
   // ---- 1. LayerNorm: wave w normalises rows w, w + 8, ...; a lane holds features 2 lane, 2 lane + 1 (ten rows at a time:
