@@ -57,6 +57,7 @@ struct EncLayer {
 struct DecLayer {
   float *ln1_g, *ln1_b, *lnc_g, *lnc_b, *ln2_g, *ln2_b;
   bf16_t *Wqkv, *Wo, *Wcq, *Wckv, *Wco, *W1, *W2;
+  bf16_t* W1_plain = nullptr;   // fc1 once more in plain row-major [F][D] for the tiled GEMM (lanes of >= 256 rows, prefill)
   float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
   bf16_t *crossK, *crossV, *selfK, *selfV;
 };
@@ -479,6 +480,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     TRY(up_bf16(w, &L.Wckv, wckv.data(), wckv.size())); TRY(up_f32(w, &L.bckv, bckv.data(), bckv.size()));
     TRY(up_bf16_packed(w, &L.Wco, cow->data.data(), D, D, 16)); TRY(up_f32(w, &L.bco, cob->data.data(), D));
     TRY(up_bf16_packed(w, &L.W1, m0w->data.data(), F, D, 16)); TRY(up_f32(w, &L.b1, m0b->data.data(), F));
+    TRY(up_bf16(w, &L.W1_plain, m0w->data.data(), m0w->data.size()));
     TRY(up_bf16_packed(w, &L.W2, m2w->data.data(), D, F, 16)); TRY(up_f32(w, &L.b2, m2b->data.data(), D));
     TRY(up_f32(w, &L.ln1_g, l1g->data.data(), D)); TRY(up_f32(w, &L.ln1_b, l1b->data.data(), D));
     TRY(up_f32(w, &L.lnc_g, lcg->data.data(), D)); TRY(up_f32(w, &L.lnc_b, lcb->data.data(), D));
@@ -924,8 +926,21 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
       TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     }
-    // MLP
-    TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, dffn, F, nullptr));
+    // MLP.  With 256 rows and more the first linear is an ordinary GEMM problem (384 x 3072 x 768): the tiled kernel shares the
+    // weight and activation tiles of a block through LDS, the skinny one re-reads them per 32-column block out of L2:
+    // pipeline step 653.1 -> 647.6 ms.  (The self-attention q|k|v projection the same way -- GEMM into an fp32 scratch plus a
+    // scatter kernel for the cache rows -- was measured too: 650.8 against 650.5 ms, not kept.)
+    static const int fc1_gemm_rows = [] { const char* e = getenv("CCX_DEC_FC1_GEMM_ROWS"); return e ? atoi(e) : 256; }();
+    if (fc1_gemm_rows > 0 && B >= fc1_gemm_rows && L.W1_plain && D % 64 == 0) {
+      TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, L.ln2_g, L.ln2_b, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream));
+      if (pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
+      GemmParams gp;
+      memset(&gp, 0, sizeof(gp));
+      gp.A = dxn; gp.lda = D; gp.W = L.W1_plain; gp.ldw = D; gp.M = B; gp.N = F; gp.K = D; gp.bias = L.b1; gp.out = dffn; gp.ldo = F;
+      TRY(ccx_launch_gemm(ctx, EPI_BF16_GELU, gp, stream));
+    } else {
+      TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, dffn, F, nullptr));
+    }
     stamp(20, 2);
     TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, dffn));
     stamp(21, 2);

@@ -307,6 +307,32 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
         m.close()
 
 
+def test_lane_of_256_rows_and_more_matches_small_batch(ccx_ctx, monkeypatch):
+    """From 256 rows per lane on (the 768-sequence decode groups of bench.py) the decoder's first MLP linear runs through the tiled
+    GEMM and the skinny linears use 32-column blocks; 264 sequences in ONE lane must still decode like a batch of 4.  The GEMM sums
+    K in another order than the skinny kernel: log-probabilities agree to 2e-3 relative, tokens exactly (the synthetic model's
+    margins are far above that)."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=264, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        m.log_mel(dev, n); m.encode(4)
+        prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
+        a = m.decode_greedy(prompts, sample_len=12)
+        big = dev.repeat(66, 1).contiguous()
+        m.log_mel(big, n * 66); m.encode(264)
+        monkeypatch.setenv("CCX_DEC_LANES", "1")
+        b = m.decode_greedy(prompts * 66, sample_len=12)
+        for i in range(264):
+            assert b[i]["tokens"] == a[i % 4]["tokens"], i
+            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 2e-3 * max(1.0, abs(a[i % 4]["sum_logprob"]))
+    finally:
+        m.close()
+
+
 def test_uneven_lane_partition_matches_small_batch(ccx_ctx, monkeypatch):
     """100 sequences in 3 lanes are cut 48 / 48 / 4: the last lane takes the small-batch kernel path, the others the
     large-batch one, each on its own stream and graph -- every sequence must still decode exactly as in a batch of 4."""
