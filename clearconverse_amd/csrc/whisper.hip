@@ -926,11 +926,14 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
       TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     }
-    // MLP.  With 256 rows and more the first linear is an ordinary GEMM problem (384 x 3072 x 768): the tiled kernel shares the
-    // weight and activation tiles of a block through LDS, the skinny one re-reads them per 32-column block out of L2:
-    // pipeline step 653.1 -> 647.6 ms.  (The self-attention q|k|v projection the same way -- GEMM into an fp32 scratch plus a
-    // scatter kernel for the cache rows -- was measured too: 650.8 against 650.5 ms, not kept.)
-    static const int fc1_gemm_rows = [] { const char* e = getenv("CCX_DEC_FC1_GEMM_ROWS"); return e ? atoi(e) : 256; }();
+    // MLP.  OPTIONAL (CCX_DEC_FC1_GEMM_ROWS=n, off by default): with n rows and more the first linear runs through the tiled GEMM,
+    // which shares the weight and activation tiles of a block through LDS where the skinny kernel re-reads them per 32-column
+    // block out of L2: pipeline step 653.1 -> 647.6 ms at n = 256.  It is off because the GEMM sums K in another order than the
+    // skinny kernel: a sequence's log-probabilities would then depend (in the last bits) on how many rows its lane or its
+    // prefill pass has, and tests/test_pinned_parity_gpu.py holds the records of a clip bit-identical whatever its batch mates.
+    // (The self-attention q|k|v projection the same way -- GEMM into an fp32 scratch plus a scatter kernel for the cache rows --
+    // was measured too: 650.8 against 650.5 ms, removed.)
+    static const int fc1_gemm_rows = [] { const char* e = getenv("CCX_DEC_FC1_GEMM_ROWS"); return e ? atoi(e) : 0; }();
     if (fc1_gemm_rows > 0 && B >= fc1_gemm_rows && L.W1_plain && D % 64 == 0) {
       TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, L.ln2_g, L.ln2_b, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream));
       if (pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }

@@ -308,10 +308,8 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
 
 
 def test_lane_of_256_rows_and_more_matches_small_batch(ccx_ctx, monkeypatch):
-    """From 256 rows per lane on (the 768-sequence decode groups of bench.py) the decoder's first MLP linear runs through the tiled
-    GEMM and the skinny linears use 32-column blocks; 264 sequences in ONE lane must still decode like a batch of 4.  The GEMM sums
-    K in another order than the skinny kernel: log-probabilities agree to 2e-3 relative, tokens exactly (the synthetic model's
-    margins are far above that)."""
+    """Lanes of 128 rows and more (the 768-sequence decode groups of bench.py: 384 per lane) use 32-column blocks in the skinny
+    linears -- another grid, the same sums: 264 sequences in ONE lane must decode exactly like a batch of 4."""
     from clearconverse_amd.whisper import WhisperModel
     dims = WhisperDims.mini(n_layer=2, n_state=128)
     sd = synthetic_whisper_state_dict(dims, seed=3)
@@ -328,7 +326,7 @@ def test_lane_of_256_rows_and_more_matches_small_batch(ccx_ctx, monkeypatch):
         b = m.decode_greedy(prompts * 66, sample_len=12)
         for i in range(264):
             assert b[i]["tokens"] == a[i % 4]["tokens"], i
-            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 2e-3 * max(1.0, abs(a[i % 4]["sum_logprob"]))
+            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-3
     finally:
         m.close()
 
