@@ -61,6 +61,7 @@ PROTOTYPES = {
     "ccx_whisper_destroy": (None, [_vp]),
     "ccx_whisper_set_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i64p]),
     "ccx_whisper_set_max_audio": (_i, [_vp, C.c_double]),
+    "ccx_whisper_share_encoder_scratch": (_i, [_vp, _vp]),
     "ccx_whisper_finalize": (_i, [_vp]),
     "ccx_whisper_set_rules": (_i, [_vp, C.POINTER(DecodeRules)]),
     "ccx_whisper_logmel": (_i, [_vp, _vp, _i64, _ip, _ip, _i, _vp, _vp]),

@@ -69,6 +69,7 @@ struct ccx_whisper {
   ccx_whisper_dims d{};
   int max_batch = 0;
   bool finalized = false;
+  ccx_whisper* scratch_donor = nullptr;   // ccx_whisper_share_encoder_scratch: log-mel / encoder workspaces of another instance
   std::map<std::string, HostTensor> staged;
   std::vector<void*> allocs;
   char* arena = nullptr;
@@ -284,7 +285,7 @@ extern "C" {
 int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch, ccx_whisper** out) {
   if (!ctx) return CCX_ERR_ARG;
   CCX_REQUIRE(ctx, dims && out, "ccx_whisper_create: null argument");
-  CCX_REQUIRE(ctx, max_batch >= 1 && max_batch <= 1024, "ccx_whisper_create: max_batch %d out of range", max_batch);
+  CCX_REQUIRE(ctx, max_batch >= 1 && max_batch <= 1536, "ccx_whisper_create: max_batch %d out of range", max_batch);
   const ccx_whisper_dims& d = *dims;
   CCX_REQUIRE(ctx, d.n_audio_state % 128 == 0 && d.n_text_state == d.n_audio_state, "whisper: n_state must be a multiple of 128 and equal for encoder/decoder");
   CCX_REQUIRE(ctx, d.n_audio_state / d.n_audio_head == 64 && d.n_text_state / d.n_text_head == 64, "whisper: head_dim must be 64");
@@ -353,6 +354,15 @@ int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds) {
   const long frames = (long)(seconds * 100.0) + 8;
   w->Fraw = (int)((frames + 31) / 32 * 32);
   if (w->Fraw < 3008) w->Fraw = 3008;
+  return CCX_OK;
+}
+
+int ccx_whisper_share_encoder_scratch(ccx_whisper* w, ccx_whisper* donor) {
+  if (!w) return CCX_ERR_ARG;
+  CCX_REQUIRE(w->ctx, donor && donor != w && donor->finalized && !w->finalized, "whisper: share_encoder_scratch needs a finalized donor and an unfinalized taker");
+  CCX_REQUIRE(w->ctx, donor->max_batch >= w->max_batch && donor->Fraw >= w->Fraw && !memcmp(&donor->d, &w->d, sizeof(w->d)),
+              "whisper: share_encoder_scratch: the donor must have the same dimensions and at least the taker's capacity");
+  w->scratch_donor = donor;
   return CCX_OK;
 }
 
@@ -492,21 +502,29 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   w->staged.clear();
 
   // ---------------- workspaces ----------------
-  TRY(dev_alloc(w, &w->lm_raw, (size_t)B * 80 * w->Fraw, true));
-  TRY(dev_alloc(w, &w->lm_max, (size_t)B, true));
-  TRY(dev_alloc(w, &w->lm_n, (size_t)B, true));
-  TRY(dev_alloc(w, &w->lm_seek, (size_t)B, true));
-  TRY(dev_alloc(w, &w->lm_seg, (size_t)B, true));
-  TRY(dev_alloc(w, &w->im2col, (size_t)B * 3000 * 256, true));
-  TRY(dev_alloc(w, &w->h1, ((size_t)B * 3002 + 2) * D, true));
-  TRY(dev_alloc(w, &w->x, (size_t)B * S * D, true));
-  TRY(dev_alloc(w, &w->xn, (size_t)B * S * D, true));
-  TRY(dev_alloc(w, &w->xa, (size_t)B * S * D, true));
-  TRY(dev_alloc(w, &w->qb, (size_t)B * H * w->Spad * 64, true));
-  TRY(dev_alloc(w, &w->kb, (size_t)B * H * w->Spad * 64, true));
-  TRY(dev_alloc(w, &w->vtb, (size_t)B * H * 64 * w->Spad, true));
-  TRY(dev_alloc(w, &w->attn, (size_t)B * S * D, true));
-  TRY(dev_alloc(w, &w->ffn, (size_t)B * S * F, true));
+  // log-mel and encoder: only live between ccx_whisper_logmel and the end of ccx_whisper_encode (the cross-KV it leaves behind is
+  // per instance), so two instances whose log-mel / encode calls are ordered on ONE stream may share them (32 GB at 768 windows)
+  if (ccx_whisper* dn = w->scratch_donor) {
+    w->lm_raw = dn->lm_raw; w->lm_max = dn->lm_max; w->lm_n = dn->lm_n; w->lm_seek = dn->lm_seek; w->lm_seg = dn->lm_seg;
+    w->im2col = dn->im2col; w->h1 = dn->h1; w->x = dn->x; w->xn = dn->xn; w->xa = dn->xa;
+    w->qb = dn->qb; w->kb = dn->kb; w->vtb = dn->vtb; w->attn = dn->attn; w->ffn = dn->ffn;
+  } else {
+    TRY(dev_alloc(w, &w->lm_raw, (size_t)B * 80 * w->Fraw, true));
+    TRY(dev_alloc(w, &w->lm_max, (size_t)B, true));
+    TRY(dev_alloc(w, &w->lm_n, (size_t)B, true));
+    TRY(dev_alloc(w, &w->lm_seek, (size_t)B, true));
+    TRY(dev_alloc(w, &w->lm_seg, (size_t)B, true));
+    TRY(dev_alloc(w, &w->im2col, (size_t)B * 3000 * 256, true));
+    TRY(dev_alloc(w, &w->h1, ((size_t)B * 3002 + 2) * D, true));
+    TRY(dev_alloc(w, &w->x, (size_t)B * S * D, true));
+    TRY(dev_alloc(w, &w->xn, (size_t)B * S * D, true));
+    TRY(dev_alloc(w, &w->xa, (size_t)B * S * D, true));
+    TRY(dev_alloc(w, &w->qb, (size_t)B * H * w->Spad * 64, true));
+    TRY(dev_alloc(w, &w->kb, (size_t)B * H * w->Spad * 64, true));
+    TRY(dev_alloc(w, &w->vtb, (size_t)B * H * 64 * w->Spad, true));
+    TRY(dev_alloc(w, &w->attn, (size_t)B * S * D, true));
+    TRY(dev_alloc(w, &w->ffn, (size_t)B * S * F, true));
+  }
 
   TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dx2, (size_t)B * D, true));

@@ -60,7 +60,7 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
                 seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None,
-                resnet_max_chunks: int = 96, whisper_instances: int = 1) -> Dict[str, object]:
+                resnet_max_chunks: int = 96, whisper_instances: int = 1, share_encoder_scratch: bool = True) -> Dict[str, object]:
     if not torch.cuda.is_available():
         raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
     dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
@@ -71,8 +71,12 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
     sd_ = SepDims(**W["sep_dims"])      # the geometry the separator weights were built with (broadcast manifest included)
     # whisper_instances = 2: the software-pipelined batch driver (batch.py) encodes batch i + 1 into one instance while batch i
     # is still decoding out of the other (each holds its own cross-KV, workspaces and step graphs; the weights are 0.5 GB)
-    whispers = [WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds)
-                for _ in range(max(1, int(whisper_instances)))]
+    # The further instances take the first one's log-mel / encoder workspaces (share_encoder_scratch; 32 GB at 768 windows): those
+    # are only live inside log_mel / encode, and the pipelined driver orders every instance's log_mel / encode on one stream.
+    whispers = [WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds)]
+    for _ in range(1, max(1, int(whisper_instances))):
+        whispers.append(WhisperModel(wd, wsd, max_batch=whisper_batch, device=dev_index, ctx=ctx, max_audio_seconds=max_audio_seconds,
+                                     share_encoder_scratch_with=whispers[0] if share_encoder_scratch else None))
     whisper = whispers[0]
     separator = SepformerSeparator(sd_, W["sepformer"], max_tokens=sep_tokens, max_utts=64,
                                    device=dev_index, ctx=ctx)

@@ -33,7 +33,8 @@ INPUT_STRIDE = 2       # mel frames per encoder position
 class WhisperModel:
     def __init__(self, dims: WhisperDims, state_dict: Dict[str, torch.Tensor], max_batch: int = 8,
                  device: int = 0, rules: Optional[DecodeRules] = None, tokenizer=None,
-                 ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0):
+                 ctx: Optional[_lib.Context] = None, max_audio_seconds: float = 30.0,
+                 share_encoder_scratch_with: Optional["WhisperModel"] = None):
         if not torch.cuda.is_available():
             raise _lib.CcxError("WhisperModel needs a ROCm GPU: the HIP path has no CPU fallback")
         self.dims = dims
@@ -51,6 +52,12 @@ class WhisperModel:
         self.max_audio_seconds = float(max_audio_seconds)
         self.sample_seed, self._sample_calls = 0, 0     # temperature > 0: Philox seed and per-call counter
         self.ctx.check(self.lib.ccx_whisper_set_max_audio(self.handle, self.max_audio_seconds), "ccx_whisper_set_max_audio")
+        # log-mel / encoder workspaces of another instance (kept alive here): only for instances whose log_mel / encode calls
+        # are ordered on one stream, as in BatchPipeline.run_pinned_pipelined (include/ccx.h)
+        self._scratch_donor = share_encoder_scratch_with
+        if share_encoder_scratch_with is not None:
+            self.ctx.check(self.lib.ccx_whisper_share_encoder_scratch(self.handle, share_encoder_scratch_with.handle),
+                           "ccx_whisper_share_encoder_scratch")
         self._load(state_dict)
         self.set_rules(self.rules)
 

@@ -105,6 +105,11 @@ int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, i
 /* Longest clip (seconds) ccx_whisper_logmel must accept (default 30); call before finalize.  The log-mel of the
  * whole clip is normalised with its global maximum, exactly like whisper.audio.log_mel_spectrogram. */
 int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds);
+/* Optional, before finalize: take the log-mel / encoder workspaces of `donor` (finalized, same dimensions, at least this
+ * instance's capacity) instead of allocating them.  They are only live between ccx_whisper_logmel and the end of
+ * ccx_whisper_encode, so this is safe exactly when the two instances' log-mel / encode calls are ordered on one stream (the
+ * software-pipelined batch driver: one instance decodes while the other encodes).  The donor must outlive the taker. */
+int ccx_whisper_share_encoder_scratch(ccx_whisper* w, ccx_whisper* donor);
 /* Checks every tensor is present, builds the fused/bf16 device layouts, uploads. */
 int ccx_whisper_finalize(ccx_whisper* w);
 int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* rules);
