@@ -119,8 +119,42 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def lane_cross_attention_in_situ(path, bytes_per_sequence):
+    """Reduce the decode-lane trace of libccx (ccx_whisper_trace_lanes; the format tools/decode_stamps.py reads) of the LAST decode
+    in `path`: per lane the median time between the stamp in front of a layer's cross attention and the one behind it, while the
+    other lanes run their own steps (graph replay, real concurrency -- what neither HIP events nor the tracer can see)."""
+    blocks, cur = [], None
+    for line in open(path):
+        q = line.split()
+        if q and q[0] == "decode":
+            cur = {"B": int(q[2]), "lanes": {}}
+            blocks.append(cur)
+        elif q and q[0] == "lane" and cur is not None:
+            v = np.array([int(x) for x in q[3:]], dtype=np.uint64)
+            cur["lanes"][int(q[1])] = ((v >> np.uint64(8)).astype(np.int64) * 10, (v & np.uint64(255)).astype(np.int64))   # ns, tag
+    if not blocks or not blocks[-1]["lanes"]:
+        return None
+    blk = blocks[-1]
+    nl, B = len(blk["lanes"]), blk["B"]
+    per = -(-(-(-B // nl)) // 16) * 16          # lane sizes as ccx_whisper_decode cuts them: multiples of one MFMA row tile
+    out = []
+    for lane, (t, tag) in sorted(blk["lanes"].items()):
+        d = (t[1:] - t[:-1])[tag[1:] == 2] / 1e3                 # us, intervals that END at a tag-2 stamp = one cross attention
+        d = d[len(d) // 4:]                                        # skip the eager first step and the capture pass
+        rows = min(per, B - lane * per)
+        if len(d) and rows > 0:
+            out.append(dict(lane=lane, sequences=rows, launches=int(len(d)), median_us=float(np.median(d)), p90_us=float(np.percentile(d, 90)),
+                            gbs=rows * bytes_per_sequence / (float(np.median(d)) * 1e-6) / 1e9))
+    return out or None
+
+
 def main():
-    os.environ.setdefault("CCX_PROF_SHAPES", "1")      # per-shape GEMM labels in the profiled step (folded back below)
+    # every CCX_* switch of libccx found in the environment goes into the JSON line; the diagnostic ones that make results garbage
+    # are refused (tools/README.md, "Measurement switches")
+    ccx_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("CCX_")}
+    if "CCX_ABLATE" in ccx_env:
+        raise SystemExit("bench.py: CCX_ABLATE drops kernels from the decode step (diagnostic, results are garbage) -- unset it")
+    os.environ.setdefault("CCX_PROF_SHAPES", "1")      # per-shape GEMM / LayerNorm labels in the profiled step (labels only; folded back below)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: two 4-batch decode groups timed behind one warm-up group -- a single group has no earlier decode for its front
@@ -133,6 +167,8 @@ def main():
     ap.add_argument("--whisper-group", type=int, default=192, help="sequences decoded together in the pipeline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="one extra (untimed) step with a sync after every stage")
+    ap.add_argument("--no-comparisons", action="store_true",
+                    help="skip the span-1 and sequential comparison legs after the timed region (profiling runs: fewer launch shapes per symbol)")
     ap.add_argument("--decode-span", type=int, default=4,
                     help="pipelined schedule: batches whose Whisper windows are encoded and decoded together (1 = one decode group per batch)")
     ap.add_argument("--schedule", choices=("pipelined", "sequential"), default="pipelined",
@@ -200,7 +236,8 @@ def main():
             args.whisper_group = max(args.whisper_group, 6 * B * args.decode_span)
         models = load_models(None, local_rank, whisper_batch=args.whisper_group, ctx=ctx, seed=0, state_dicts=sds,
                              seg_max_crops=52 * B + 16, seg_max_seconds=300.0 * B, emb_max_crops=44 * B,
-                             resnet_max_chunks=21 * B, whisper_instances=2 if args.schedule == "pipelined" else 1, max_audio_seconds=30.0)
+                             resnet_max_chunks=21 * B, whisper_instances=2 if args.schedule == "pipelined" else 1, max_audio_seconds=30.0,
+                             gate_max_clips=B)
         del sds
         sd = None
         bp = BatchPipeline(models, whisper_group=args.whisper_group, sample_len=args.sample_len)
@@ -256,7 +293,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     seq_ms = span1_ms = None
-    if pipelined and args.decode_span > 1:
+    if pipelined and args.decode_span > 1 and not args.no_comparisons:
         # the same pipeline with one decode group per batch, for comparison (untimed for `value`)
         n1 = min(4, max(2, args.steps))
         torch.cuda.synchronize()
@@ -264,7 +301,7 @@ def main():
         bp.run_pinned_pipelined([audio] * n1, span=1)
         torch.cuda.synchronize()
         span1_ms = (time.perf_counter() - ts) * 1e3 / n1
-    if pipelined:
+    if pipelined and not args.no_comparisons:
         # the sequential schedule of the same batch, for comparison (untimed for `value`)
         nseq = min(3, max(1, args.steps))
         torch.cuda.synchronize()
@@ -299,6 +336,22 @@ def main():
     probe = ctx.prof_records()
     ctx.prof_enable(False)
     del os.environ["CCX_NO_GRAPH"]
+    # ---- the same launch IN SITU: graph replay, all lanes of the group stepping concurrently (in-graph time stamps around every
+    # layer's cross attention; the solo figure above times one launch at a time)
+    in_situ = None
+    if rank == 0:
+        import tempfile
+        tr = os.path.join(tempfile.gettempdir(), f"ccx_lane_trace_{os.getpid()}.txt")
+        if os.path.exists(tr):
+            os.remove(tr)
+        wm.trace_lanes(tr, 1)
+        for _ in range(2):                                   # the first decode captures the stamped step graphs, the second replays them
+            wm.decode_greedy([[rules.sot]] * Bd, sample_len=24)
+        torch.cuda.synchronize()
+        wm.trace_lanes(None)
+        if os.path.exists(tr):
+            in_situ = lane_cross_attention_in_situ(tr, dims.n_text_head * dims.n_audio_ctx * (dims.n_text_state // dims.n_text_head) * 2 * 2)
+            os.remove(tr)
     # decode launches per pipeline step: a unit of `span` batches is decoded in ceil(6 B span / Bd) groups
     decode_steps_per_step = (args.sample_len + 1) * (((6 * B * span + Bd - 1) // Bd) / span if pipeline else 1)
 
@@ -316,7 +369,8 @@ def main():
     value = audio_s / dt
 
     if rank == 0:
-        # ---- roofline of the dominant eagerly-launched kernel (HIP events, timed region) ----
+        # ---- roofline of the kernel with the largest time per step (HIP events on the launch stream: eager kernels during one extra
+        # step right after the timed region, graph-resident decode kernels during an eager re-run of a few decode steps) ----
         def aggregate_records(rs):
             out_ = {}
             for name, fl, by, ms in rs:
@@ -336,11 +390,14 @@ def main():
                             avg_launch_us=round(ms * 1e3 / cnt_, 2), flops_per_launch=fl / cnt_, measured=where)
             ach = by / (ms * 1e-3) / 1e9
             traffic = pmc.get("hbm_bytes_per_launch")
-            if traffic is not None and "sequences_per_launch" in pmc:
-                # the counter passes decode the group in one lane (192 sequences per launch): scale to this run's launches
+            if traffic is not None and pmc.get("sequences_per_launch"):
+                # measured at `sequences_per_launch` per launch (counter passes serialise the lanes); equal to this run's launch
+                # shape when the newest committed pass was taken at it, scaled by the sequence count otherwise
                 traffic = traffic / pmc["sequences_per_launch"] * (by / cnt_) / (dims.n_audio_ctx * dims.n_text_state * 2 * 2)
             return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic, launches=cnt_,
+                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic,
+                        traffic_source=(f"{pfs[-1].name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {pmc.get('sequences_per_launch')} sequences per launch there"
+                                        if traffic is not None and pfs else None), launches=cnt_,
                         avg_launch_us=round(ms * 1e3 / cnt_, 2), bytes_per_launch=by / cnt_, measured=where)
 
         # GEMM launches carry per-shape labels ("gemm<epi1,256x256> M=288000 N=3072 K=768 taps=1"): the encoder's are the ones whose
@@ -350,11 +407,14 @@ def main():
         enc_fl = enc_ms = 0.0
         enc_n = 0
         folded = []
+        recs0 = recs
         for name, fl, by, ms in recs:
             if name.startswith("gemm<"):
                 if any(t in name for t in enc_rows):
                     enc_fl += fl; enc_ms += ms; enc_n += 1
                 name = "gemm_bf16_nt_kernel"
+            elif name.startswith("layernorm_kernel"):
+                name = "layernorm_kernel"
             folded.append((name, fl, by, ms))
         recs = folded
         agg = aggregate_records(recs)
@@ -374,6 +434,15 @@ def main():
             cnt_, fl, by, ms = src[name]
             roof = roof_entry(name, cnt_, fl, by, ms, per_step[name][1])
             roof["ms_per_step"] = round(per_step[name][0], 2)
+            if name.startswith("dec_cross_stream_kernel") and in_situ:
+                # the same kernel inside the replayed step graphs with every lane of the group running: bytes of a lane's launch /
+                # median stamp-to-stamp time, averaged over the lanes
+                gbs = float(np.mean([l["gbs"] for l in in_situ]))
+                roof["achieved_in_situ"] = round(gbs, 1)
+                roof["frac_in_situ"] = round(gbs / PEAK_HBM_GBS, 4)
+                roof["in_situ"] = dict(lanes=[{k: (round(v, 1) if isinstance(v, float) else v) for k, v in l.items()} for l in in_situ],
+                                       measured="in-graph s_memrealtime stamps around every layer's cross attention (ccx_whisper_trace_lanes), "
+                                                f"graph replay of a {Bd}-sequence group, all lanes concurrent; includes the ~2 us stamp nodes")
         if "gemm_bf16_nt_kernel" in agg and (roof is None or roof["kernel"] != "gemm_bf16_nt_kernel"):
             cnt_, fl, by, ms = agg["gemm_bf16_nt_kernel"]
             roof_mfma = roof_entry("gemm_bf16_nt_kernel", cnt_, fl, by, ms, where_eager)
@@ -382,6 +451,18 @@ def main():
                 ach = enc_fl / (enc_ms * 1e-3) / 1e12
                 roof_mfma["whisper_encoder_gemms"] = dict(achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                                                           launches=enc_n, ms_per_step=round(enc_ms / prof_steps, 2))
+                # the WHOLE encoder: its GEMMs + attention + LayerNorms (every launch between log-mel and the decoder) against the
+                # algorithmic 386.7 GFLOP per window (encoder 344.2 + cross-KV projection 42.5)
+                att_ms = sum(ms for n_, _, _, ms in recs if n_ == "enc_attention_kernel")
+                ln_ms = sum(ms for n_, _, _, ms in recs0 if n_.startswith("layernorm_kernel M=") and f" M={nwin * dims.n_audio_ctx} " in n_ + " ")
+                wins = (6 * B if pipeline else B) * prof_steps
+                tot_ms = enc_ms + att_ms + ln_ms
+                fl_tot = wins * float(sum(enc_flops_per_window(dims)))
+                ach_t = fl_tot / (tot_ms * 1e-3) / 1e12
+                roof_mfma["whisper_encoder_total"] = dict(achieved=round(ach_t, 2), unit="TFLOP/s", frac=round(ach_t / PEAK_MFMA_BF16_TFLOPS, 4),
+                                                          gemm_ms=round(enc_ms / prof_steps, 2), attention_ms=round(att_ms / prof_steps, 2),
+                                                          layernorm_ms=round(ln_ms / prof_steps, 2), windows_per_step=wins // prof_steps,
+                                                          gflop_per_window=round(sum(enc_flops_per_window(dims)) / 1e9, 1))
         stage_ms = {k: round(v[3] / prof_steps, 3) for k, v in agg.items()}
         stage_ms.update({k: round(v[0], 3) for k, v in per_step.items()})
 
@@ -447,6 +528,7 @@ def main():
             "roofline_mfma": roof_mfma,
             "cpu_baseline": cpu,
             "kernel_ms_per_step": stage_ms,
+            "ccx_env": dict(ccx_env, **({} if "CCX_PROF_SHAPES" in ccx_env else {"CCX_PROF_SHAPES": "1 (set by bench.py: labels of the profiled step only)"})),
             "model_load_ms": round(load_ms, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 1),
             "hbm_used_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),

@@ -107,9 +107,11 @@ class BatchPipeline:
         t = self._mark("load_audio_gate", t, timed)
         # 2. VAD and diarization on the RAW clips (computed, not steering)
         items = [{"waveform": audio[b], "sample_rate": SR} for b in range(B)]
-        n_vad = sum(len(a) for a in m["vad_pipeline"].batch(items))
+        vad_ann = m["vad_pipeline"].batch(items)
+        n_vad = sum(len(a) for a in vad_ann)
         t = self._mark("vad", t, timed)
-        n_diar = sum(len(a) for a in m["diarization"].batch(items, min_speakers=1, max_speakers=2))
+        diar_ann = m["diarization"].batch(items, min_speakers=1, max_speakers=2)
+        n_diar = sum(len(a) for a in diar_ann)
         t = self._mark("diarization", t, timed)
         # 3. speaker profiles from the scheduled turns (all >= 0.75 s): gate each crop, normalise, embed (A8)
         sched = [(spk, int(s * SR), int(e * SR)) for spk, s, e in SCHEDULE_30S]
@@ -191,7 +193,7 @@ class BatchPipeline:
                   win_sims=win_sims, t=t)
         if debug:
             st["dbg"] = dict(den=den, pe_c=pe_c, var_c=var_c, prof_all=prof_all, owner=owner, sep=sep, rn=rn, se=se, pr=pr, pick=pick,
-                             regions=regions, reg=reg)
+                             regions=regions, reg=reg, vad_ann=vad_ann, diar_ann=diar_ann)
         return st
 
     def _finish(self, st: dict, all_txt: List[dict], prompt_ids: Optional[list], timed: bool) -> Dict[str, object]:
@@ -212,7 +214,9 @@ class BatchPipeline:
                        window_sims_full=win_sims.cpu(), window_owner=list(owner), separated=sep.cpu(), region_len=list(rn),
                        source_sims=torch.stack([torch.nn.functional.cosine_similarity(se[k], pr, dim=1) for k in range(2)], dim=1).cpu(),
                        pick=[int(x) for x in pick], prompt_ids=prompt_ids, whisper_inputs=[c.cpu() for c in reg_crops + best],
-                       regions=[(b, spk, s, e) for b, spk, s, e in regions], regular=[(b, spk, s, e) for b, spk, s, e in reg])
+                       regions=[(b, spk, s, e) for b, spk, s, e in regions], regular=[(b, spk, s, e) for b, spk, s, e in reg],
+                       vad=[[(sg.start, sg.end) for sg, _ in a.itertracks()] for a in d["vad_ann"]],
+                       diarization=[[(sg.start, sg.end, l) for sg, _, l in a.itertracks(yield_label=True)] for a in d["diar_ann"]])
         return dict(**dbg, n_clips=B, audio_seconds=30.0 * B, whisper_calls=len(reg_crops) + len(best), tokens=sum(len(r["tokens"]) for r in reg_txt + ov_txt),
                     embeds=st["embeds"], separator_calls=st["separator_calls"],
                     vad_regions=st["n_vad"], diar_turns=st["n_diar"], records=reg_txt + ov_txt, sims=sims.cpu().tolist(), window_sims=int(win_sims.shape[0]))
@@ -316,13 +320,14 @@ def shard_clip_indices(n_clips: int, rank: int, world: int) -> List[int]:
     return [i for i in range(n_clips) if i % world == rank]
 
 
-def broadcast_weights(state_dicts: Optional[dict], src: int = 0, device="cpu") -> dict:
+def broadcast_weights(state_dicts: Optional[dict], src: int = 0, device="cpu", force_collective: bool = False) -> dict:
     """The start-of-job collective (C1): rank `src` holds the weights of every model
     (models.build_state_dicts); all tensors are packed into ONE byte blob and sent with ONE broadcast (RCCL: a direct
     1 -> N-1 send over the xGMI links), the small manifest (names / shapes / dtypes / non-tensor entries) as an object
-    broadcast before it.  Returns the same nested dict on every rank (host tensors: views of one host copy of the received blob)."""
+    broadcast before it.  Returns the same nested dict on every rank (host tensors: views of one host copy of the received blob).
+    `force_collective`: pack, broadcast and unpack even in a one-rank group (lets RCCL run this code on a single GPU)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         if state_dicts is None:
             raise ValueError("broadcast_weights: no process group and no local weights")
         return state_dicts

@@ -15,8 +15,10 @@ int ccx_fail(ccx_ctx* ctx, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx) ctx->last_error = buf;
-  else g_create_error = buf;
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->last_error = buf;
+  } else g_create_error = buf;
   return code;
 }
 

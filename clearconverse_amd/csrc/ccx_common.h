@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,24 +37,28 @@ struct ccx_ctx {
   std::string last_error;
   bool prof_on = false;
   std::vector<ccx_prof_rec> prof;
+  std::mutex mu;   // guards prof and last_error: the software-pipelined batch driver calls into one context from two host threads
 };
 
 // RAII: records start/stop events around a kernel launch when ctx->prof_on (never inside a
 // stream capture: the caller passes capturing=true there).
 struct ccx_prof_scope {
-  ccx_ctx* ctx; hipStream_t stream; bool active; size_t idx;
-  ccx_prof_scope(ccx_ctx* c, hipStream_t s, const char* name, double flops, double bytes) : ctx(c), stream(s), active(false), idx(0) {
+  ccx_ctx* ctx; hipStream_t stream; bool active; hipEvent_t stop;
+  ccx_prof_scope(ccx_ctx* c, hipStream_t s, const char* name, double flops, double bytes) : ctx(c), stream(s), active(false), stop(nullptr) {
     if (!c || !c->prof_on) return;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
     ccx_prof_rec r{name, flops, bytes, nullptr, nullptr};
     if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
     hipEventRecord(r.start, s);
-    c->prof.push_back(r);
-    idx = c->prof.size() - 1;
+    stop = r.stop;                       // kept here: another thread's push_back may move the vector's storage
+    {
+      std::lock_guard<std::mutex> lk(c->mu);
+      c->prof.push_back(r);
+    }
     active = true;
   }
-  ~ccx_prof_scope() { if (active) hipEventRecord(ctx->prof[idx].stop, stream); }
+  ~ccx_prof_scope() { if (active) hipEventRecord(stop, stream); }
 };
 
 // Set ctx error text and return the code (host side).

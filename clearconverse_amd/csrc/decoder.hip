@@ -1017,16 +1017,28 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
     // self-attention length varies per row and is known on the device only: priced at one key (q in, one K/V row, out), so that
     // the launch shows up in the per-kernel times without claiming traffic it may not have moved
     const double keys = p.pos ? 1.0 : (double)p.T;
-    // the cross attention keeps its profile label whatever variant runs (self attention: <true> with pos)
-    ccx_prof_scope ps(ctx, stream, p.pos ? "dec_attention_kernel<true>" : (p.rows_per_seq > 1 ? "dec_cross_prefill" : "dec_attention_kernel<false>"),
-                      4.0 * B * p.H * keys * 64 * (p.rows_per_seq > 1 && !p.pos ? p.rows_per_seq : 1),
-                      (double)B * p.H * keys * 64 * 2 * 2);
     // pieces per wave: keys per block / 4 waves, rounded up to 32 (the kernel's own formula)
     const int np_need = p.pos ? 0 : ((ccx_cdiv(ccx_cdiv(p.T, nsplit), 4) + 31) / 32);
+    static const int rb_env = [] { const char* e = getenv("CCX_PREFILL_ROWS_PER_BLOCK"); return e ? atoi(e) : 4; }();
+    // profile label = the symbol that runs (rocprofv3's kernel trace shows the same name), self attention marked as such
+    const char* label;
+    const int npi = np_need <= 4 ? 0 : (np_need <= 6 ? 1 : 2);
+    if (p.pos) label = final_out ? "dec_attention_kernel<true> (self)" : "dec_attention_kernel<false> (self)";
+    else if (p.rows_per_seq > 1) {
+      static const char* const pf4[3] = {"dec_cross_prefill_kernel<4,4>", "dec_cross_prefill_kernel<6,4>", "dec_cross_prefill_kernel<12,4>"};
+      static const char* const pf1[3] = {"dec_cross_stream_kernel<true,4,true>", "dec_cross_stream_kernel<true,6,true>", "dec_cross_stream_kernel<true,12,true>"};
+      label = (rb_env == 4 && p.rows_per_seq >= 3) ? pf4[npi] : pf1[npi];
+    } else if (p.stream_mode && np_need <= 12) {
+      static const char* const st[2][3] = {{"dec_cross_stream_kernel<false,4,false>", "dec_cross_stream_kernel<false,6,false>", "dec_cross_stream_kernel<false,12,false>"},
+                                           {"dec_cross_stream_kernel<true,4,false>", "dec_cross_stream_kernel<true,6,false>", "dec_cross_stream_kernel<true,12,false>"}};
+      label = st[final_out ? 1 : 0][npi];
+    } else label = final_out ? "dec_attention_kernel<true> (cross)" : "dec_attention_kernel<false> (cross)";
+    ccx_prof_scope ps(ctx, stream, label,
+                      4.0 * B * p.H * keys * 64 * (p.rows_per_seq > 1 && !p.pos ? p.rows_per_seq : 1),
+                      (double)B * p.H * keys * 64 * 2 * 2);
     if (p.rows_per_seq > 1 && !p.pos) {
       // prompt prefill: B = sequences here, one block per (sequence, head, prompt row), whole key range per block
       CCX_REQUIRE(ctx, nsplit == 1 && final_out && np_need <= 12, "dec_attention: the prefill cross attention takes the whole key range (T <= 1536)");
-      static const int rb_env = [] { const char* e = getenv("CCX_PREFILL_ROWS_PER_BLOCK"); return e ? atoi(e) : 4; }();
       if (rb_env == 4 && p.rows_per_seq >= 3) {
         // four prompt rows per block: the K/V of a (sequence, head) comes out of L2 once per four rows
         dim3 g4(B * p.H * ccx_cdiv(p.rows_per_seq, 4), 1);

@@ -1,6 +1,9 @@
 // elementwise.hip -- LayerNorm (fp32 statistics, bf16 output for the following MFMA GEMM) and
 // conversion helpers.  HBM-bound: one wave per row, 16-byte loads, 8/16-byte stores.
 #include "elementwise.h"
+#include <map>
+#include <mutex>
+#include <string>
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma,
@@ -131,6 +134,17 @@ int ccx_launch_layernorm(ccx_ctx* ctx, const float* x, long ldx, const float* ga
                          bf16_t* out_bf16, float* out_f32, long ldo, int M, int D, float eps, hipStream_t stream) {
   CCX_REQUIRE(ctx, M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
   CCX_REQUIRE(ctx, ldx % 4 == 0 && ldo % 4 == 0, "layernorm: ld must be a multiple of 4");
+  static const bool by_shape = getenv("CCX_PROF_SHAPES") != nullptr;
+  const char* label = "layernorm_kernel";
+  if (by_shape && ctx->prof_on) {
+    static std::mutex mu;
+    static std::map<std::string, std::string> names;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "layernorm_kernel M=%d D=%d", M, D);
+    std::lock_guard<std::mutex> lk(mu);
+    label = names.emplace(buf, buf).first->second.c_str();
+  }
+  ccx_prof_scope ps(ctx, stream, label, 0.0, (double)M * D * (4.0 + (out_bf16 ? 2.0 : 0.0) + (out_f32 ? 4.0 : 0.0)));
   hipLaunchKernelGGL(layernorm_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, ldx, gamma, beta, out_bf16,
                      out_f32, ldo, M, D, eps);
   CCX_CHECK_LAUNCH(ctx);

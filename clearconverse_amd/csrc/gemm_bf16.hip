@@ -624,9 +624,11 @@ static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream)
     static const bool by_shape = getenv("CCX_PROF_SHAPES") != nullptr;
     const char* label = "gemm_bf16_nt_kernel";
     if (by_shape && ctx->prof_on) {
+      static std::mutex mu;
       static std::map<std::string, std::string> names;
       char buf[160];
       snprintf(buf, sizeof(buf), "gemm<epi%d,%dx%d> M=%d N=%d K=%d taps=%d", EPI, TBM, TBN, p.M, p.N, p.K, p.ntaps > 1 ? p.ntaps : 1);
+      std::lock_guard<std::mutex> lk(mu);
       label = names.emplace(buf, buf).first->second.c_str();
     }
     ccx_prof_scope ps(ctx, stream, label, 2.0 * p.M * (double)p.N * kt,
@@ -652,9 +654,11 @@ static int launch_phased(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) 
     static const bool by_shape = getenv("CCX_PROF_SHAPES") != nullptr;
     const char* label = "gemm_bf16_nt_kernel";
     if (by_shape && ctx->prof_on) {
+      static std::mutex mu;
       static std::map<std::string, std::string> names;
       char buf[160];
       snprintf(buf, sizeof(buf), "gemm<epi%d,256x256> M=%d N=%d K=%d taps=%d", EPI, p.M, p.N, p.K, p.ntaps > 1 ? p.ntaps : 1);
+      std::lock_guard<std::mutex> lk(mu);
       label = names.emplace(buf, buf).first->second.c_str();
     }
     ccx_prof_scope ps(ctx, stream, label, 2.0 * p.M * (double)p.N * kt,

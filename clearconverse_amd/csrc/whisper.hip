@@ -70,6 +70,10 @@ struct ccx_whisper {
   int max_batch = 0;
   bool finalized = false;
   ccx_whisper* scratch_donor = nullptr;   // ccx_whisper_share_encoder_scratch: log-mel / encoder workspaces of another instance
+  int scratch_takers = 0;                 // instances that borrowed THIS instance's workspaces and are still alive
+  bool destroy_pending = false;           // ccx_whisper_destroy was called while takers were alive: freed with the last taker
+  hipEvent_t scratch_free = nullptr;      // (donor) recorded at the end of every encode of the group; every log-mel / set_mel of the
+                                          // group waits for it, so that users of the shared workspaces are ordered on ANY streams
   std::map<std::string, HostTensor> staged;
   std::vector<void*> allocs;
   char* arena = nullptr;
@@ -132,8 +136,11 @@ struct ccx_whisper {
                                              // queue run strictly one after the other, so lanes are picked by a probe
   std::map<hipStream_t, std::vector<hipStream_t>> lane_sets;   // lane-0 stream -> streams that overlap with it and each other
   int* probe_sink = nullptr;
-  unsigned long long* stamps = nullptr;      // [kMaxLanes][kStampCap] diagnostic trace (CCX_DEC_STAMPS)
+  unsigned long long* stamps = nullptr;      // [kMaxLanes][kStampCap] diagnostic trace (ccx_whisper_trace_lanes / CCX_DEC_STAMPS)
   int* stamp_count = nullptr;                // [kMaxLanes]
+  bool stamps_on = false;                    // stamp nodes are captured into the step graphs while set
+  int stamp_level = 1;
+  std::string stamp_path;
   static constexpr int kStampCap = 1 << 16;
   hipEvent_t lane_start[kMaxLanes] = {}, lane_poll[2][kMaxLanes] = {};
   int* poll_host = nullptr;                  // pinned [2][kMaxLanes]
@@ -305,6 +312,15 @@ int ccx_whisper_create(ccx_ctx* ctx, const ccx_whisper_dims* dims, int max_batch
 
 void ccx_whisper_destroy(ccx_whisper* w) {
   if (!w) return;
+  if (w->scratch_takers > 0) {      // a taker still points into this instance's workspaces: keep everything until it is gone
+    w->destroy_pending = true;
+    return;
+  }
+  if (ccx_whisper* dn = w->scratch_donor) {
+    w->scratch_donor = nullptr;
+    if (--dn->scratch_takers == 0 && dn->destroy_pending) ccx_whisper_destroy(dn);
+  }
+  if (w->scratch_free) hipEventDestroy(w->scratch_free);
   for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
   if (w->own_stream) hipStreamDestroy(w->own_stream);
   if (w->own_event) hipEventDestroy(w->own_event);
@@ -362,7 +378,9 @@ int ccx_whisper_share_encoder_scratch(ccx_whisper* w, ccx_whisper* donor) {
   CCX_REQUIRE(w->ctx, donor && donor != w && donor->finalized && !w->finalized, "whisper: share_encoder_scratch needs a finalized donor and an unfinalized taker");
   CCX_REQUIRE(w->ctx, donor->max_batch >= w->max_batch && donor->Fraw >= w->Fraw && !memcmp(&donor->d, &w->d, sizeof(w->d)),
               "whisper: share_encoder_scratch: the donor must have the same dimensions and at least the taker's capacity");
+  if (!donor->scratch_free) CCX_HIP(w->ctx, hipEventCreateWithFlags(&donor->scratch_free, hipEventDisableTiming));
   w->scratch_donor = donor;
+  donor->scratch_takers++;
   return CCX_OK;
 }
 
@@ -384,6 +402,18 @@ int ccx_whisper_set_rules(ccx_whisper* w, const ccx_decode_rules* r) {
   w->rules.suppress = nullptr;
   w->rules_set = true;
   // captured step graphs bake the rule ids into the select kernel's parameters: drop them
+  for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
+  w->graphs.clear();
+  return CCX_OK;
+}
+
+int ccx_whisper_trace_lanes(ccx_whisper* w, const char* path, int level) {
+  CCX_REQUIRE(w->ctx, w->finalized, "whisper: trace_lanes before finalize");
+  w->stamps_on = path != nullptr && path[0] != 0;
+  w->stamp_path = w->stamps_on ? path : "";
+  w->stamp_level = level >= 2 ? 2 : 1;
+  CCX_HIP(w->ctx, hipMemset(w->stamp_count, 0, ccx_whisper::kMaxLanes * 4));
+  // the stamp kernels are nodes of the captured step graphs: drop the graphs so that the next decode captures the other kind
   for (auto& g : w->graphs) hipGraphExecDestroy(g.second);
   w->graphs.clear();
   return CCX_OK;
@@ -567,12 +597,29 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   }
   for (int i = 0; i < ccx_whisper::kLanePool; i++) CCX_HIP(w->ctx, hipStreamCreateWithPriority(&w->lane_pool[i], hipStreamNonBlocking, prio_greatest));
   TRY(dev_alloc(w, &w->probe_sink, (size_t)64, true));
-  if (getenv("CCX_DEC_STAMPS")) {
-    TRY(dev_alloc(w, &w->stamps, (size_t)ccx_whisper::kMaxLanes * ccx_whisper::kStampCap, true));
-    TRY(dev_alloc(w, &w->stamp_count, (size_t)ccx_whisper::kMaxLanes, true));
+  // lane trace buffers (2 MB): always there so that ccx_whisper_trace_lanes can switch the trace on later
+  TRY(dev_alloc(w, &w->stamps, (size_t)ccx_whisper::kMaxLanes * ccx_whisper::kStampCap, true));
+  TRY(dev_alloc(w, &w->stamp_count, (size_t)ccx_whisper::kMaxLanes, true));
+  if (const char* e = getenv("CCX_DEC_STAMPS")) {
+    w->stamps_on = true;
+    w->stamp_path = e;
+    if (const char* l = getenv("CCX_DEC_STAMP_LEVEL")) w->stamp_level = atoi(l);
   }
   CCX_HIP(w->ctx, hipHostMalloc((void**)&w->poll_host, 2 * ccx_whisper::kMaxLanes * sizeof(int), 0));
   w->finalized = true;
+  return CCX_OK;
+}
+
+// Shared log-mel / encoder workspaces (ccx_whisper_share_encoder_scratch): every user waits for the end of the group's previous
+// encode before it writes them, on whatever stream it runs (a no-op when all users share one stream).
+static int scratch_acquire(ccx_whisper* w, hipStream_t stream) {
+  ccx_whisper* root = w->scratch_donor ? w->scratch_donor : w;
+  if (root->scratch_free) CCX_HIP(w->ctx, hipStreamWaitEvent(stream, root->scratch_free, 0));
+  return CCX_OK;
+}
+static int scratch_release(ccx_whisper* w, hipStream_t stream) {
+  ccx_whisper* root = w->scratch_donor ? w->scratch_donor : w;
+  if (root->scratch_free) CCX_HIP(w->ctx, hipEventRecord(root->scratch_free, stream));
   return CCX_OK;
 }
 
@@ -582,6 +629,7 @@ int ccx_whisper_logmel(ccx_whisper* w, const float* audio, int64_t stride, const
   hipStream_t stream = (hipStream_t)stream_;
   CCX_REQUIRE(w->ctx, w->finalized, "whisper: not finalized");
   CCX_REQUIRE(w->ctx, audio && n_samples && B >= 1 && B <= w->max_batch, "whisper_logmel: bad arguments (B=%d, max %d)", B, w->max_batch);
+  TRY(scratch_acquire(w, stream));
   long fcomp = 32;
   for (int b = 0; b < B; b++) {
     CCX_REQUIRE(w->ctx, n_samples[b] >= 0 && n_samples[b] <= stride, "whisper_logmel: n_samples[%d]=%d exceeds stride", b, n_samples[b]);
@@ -623,6 +671,7 @@ __global__ void mel_to_im2col_kernel(const float* __restrict__ mel, bf16_t* __re
 int ccx_whisper_set_mel(ccx_whisper* w, const float* mel, int B, void* stream_) {
   if (!w) return CCX_ERR_ARG;
   CCX_REQUIRE(w->ctx, w->finalized && mel && B >= 1 && B <= w->max_batch, "whisper_set_mel: bad arguments");
+  TRY(scratch_acquire(w, (hipStream_t)stream_));
   hipLaunchKernelGGL(mel_to_im2col_kernel, dim3(750, B), dim3(1024), 0, (hipStream_t)stream_, mel, w->im2col);
   CCX_CHECK_LAUNCH(w->ctx);
   return CCX_OK;
@@ -681,6 +730,7 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
     p.first_block = 1;
     TRY(ccx_launch_gemm(ctx, EPI_HEADS, p, stream));
   }
+  TRY(scratch_release(w, stream));
   return CCX_OK;
 }
 
@@ -846,9 +896,9 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   int* pos = pre ? w->pf_pos : w->pos + b0;
   const int* row_seq = pre ? w->pf_seq : nullptr;
   const long cross_off = ro * H * w->Spad * 64, self_off = ro * H * Tc * 64;
-  static const int stamp_level = [] { const char* e = getenv("CCX_DEC_STAMP_LEVEL"); return e ? atoi(e) : 1; }();
+  const int stamp_level = w->stamp_level;
   auto stamp = [&](int tag, int level) {
-    if (w->stamps && level <= stamp_level)
+    if (w->stamps_on && level <= stamp_level)
       hipLaunchKernelGGL(dec_stamp_kernel, dim3(1), dim3(1), 0, stream, w->stamps + (size_t)lane_idx * ccx_whisper::kStampCap,
                          w->stamp_count + lane_idx, ccx_whisper::kStampCap, tag);
   };
@@ -1248,12 +1298,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     CCX_HIP(ctx, hipEventRecord(w->lane_start[i], lanes[i].s));
     CCX_HIP(ctx, hipStreamWaitEvent(stream, w->lane_start[i], 0));
   }
-  if (w->stamps) {
+  if (w->stamps_on) {
     // append this decode's trace: one line per lane "lane <i> <n> <stamp> ..." (stamp = realtime << 8 | tag), then reset
     CCX_HIP(ctx, hipStreamSynchronize(stream));
     std::vector<int> cnt(ccx_whisper::kMaxLanes);
     CCX_HIP(ctx, hipMemcpy(cnt.data(), w->stamp_count, cnt.size() * 4, hipMemcpyDeviceToHost));
-    if (FILE* f = fopen(getenv("CCX_DEC_STAMPS"), "a")) {
+    if (FILE* f = fopen(w->stamp_path.c_str(), "a")) {
       fprintf(f, "decode B %d lanes %d\n", B, nl);
       for (int i = 0; i < nl; i++) {
         const int n = cnt[i] < ccx_whisper::kStampCap ? cnt[i] : ccx_whisper::kStampCap;

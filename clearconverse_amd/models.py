@@ -60,13 +60,19 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
                 whisper_dims: Optional[WhisperDims] = None, sep_dims: Optional[SepDims] = None, seed: int = 0,
                 sep_tokens: int = 160_000, max_crops: int = 256, state_dicts: Optional[Dict[str, object]] = None,
                 seg_max_crops: Optional[int] = None, seg_max_seconds: float = 1200.0, emb_max_crops: Optional[int] = None,
-                resnet_max_chunks: int = 96, whisper_instances: int = 1, share_encoder_scratch: bool = True) -> Dict[str, object]:
+                resnet_max_chunks: int = 96, whisper_instances: int = 1, share_encoder_scratch: bool = True,
+                gate_max_clips: int = 32, gate_max_seconds: float = 30.0) -> Dict[str, object]:
     if not torch.cuda.is_available():
         raise _lib.CcxError("load_models needs a ROCm GPU: the HIP path has no CPU fallback")
     dev_index = device.index if isinstance(device, torch.device) and device.index is not None else (device if isinstance(device, int) else 0)
     ctx = ctx or _lib.Context(dev_index)
     W = state_dicts if state_dicts is not None else build_state_dicts(config, whisper_dims, sep_dims, seed)
     wd, wsd = WhisperDims(**W["whisper_dims"]), W["whisper"]
+    if state_dicts is not None:         # the geometry travels WITH the weights: a contradicting argument is an error, not ignored
+        if whisper_dims is not None and whisper_dims != wd:
+            raise ValueError(f"load_models: whisper_dims {whisper_dims} contradicts state_dicts['whisper_dims'] {wd}")
+        if sep_dims is not None and sep_dims != SepDims(**W["sep_dims"]):
+            raise ValueError(f"load_models: sep_dims {sep_dims} contradicts state_dicts['sep_dims'] {W['sep_dims']}")
     vp, dp = W.get("vad_params") or {}, W.get("diarization_params") or {}
     sd_ = SepDims(**W["sep_dims"])      # the geometry the separator weights were built with (broadcast manifest included)
     # whisper_instances = 2: the software-pipelined batch driver (batch.py) encodes batch i + 1 into one instance while batch i
@@ -92,7 +98,8 @@ def load_models(config=None, device=None, whisper_batch: int = 8, ctx: Optional[
                                max_samples=int(16000 * seg_max_seconds), device=dev_index, ctx=ctx)
     seg_vad = SegmentationNet(W["pyannet_vad"], n_classes=3, powerset=False, max_crops=seg_crops,
                               max_samples=int(16000 * seg_max_seconds), device=dev_index, ctx=ctx)
-    gate = SpectralGate(max_samples=480000, max_clips=32, device=dev_index, ctx=ctx)
+    # one launch of the spectral gate holds gate_max_clips rows of gate_max_seconds (longer inputs take the chunked path)
+    gate = SpectralGate(max_samples=int(16000 * gate_max_seconds), max_clips=int(gate_max_clips), device=dev_index, ctx=ctx)
     return {
         "ctx": ctx,
         "weights_source": W.get("whisper_source", "given"),

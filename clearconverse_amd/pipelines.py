@@ -9,7 +9,8 @@ of the reference (Pipeline.from_pretrained("pyannote/voice-activity-detection") 
 The networks (SincNet/PyanNet segmentation, WeSpeaker ResNet-34 embedder of speaker-diarization-3.1) run in libccx;
 this module is the small host-side post-net (K22 in SURVEY.md): sliding windows, powerset decoding, overlap-add
 aggregation, hysteresis binarisation, agglomerative clustering, timeline reconstruction, restated from
-recollection of pyannote.audio 3.x [UPSTREAM-RECALL].  Hyper-parameters come from the pipelines' own config.yaml when it is
+recollection of pyannote.audio 3.1 [UPSTREAM-RECALL]; the frame-by-frame restatement it is tested against is
+oracle/pyannote_pipeline_ref.py (parity unpinned: no reference fixture exists for these pipelines).  Hyper-parameters come from the pipelines' own config.yaml when it is
 on disk (weights.find_pipeline_config, wired in models.load_models); the constructor defaults are the recalled values of the
 published configs.
 """
@@ -100,34 +101,35 @@ def powerset_to_multilabel(logp: np.ndarray, n_spk: int = 3, max_set: int = 2) -
     return table[np.argmax(logp, axis=-1)]
 
 
-def aggregate(chunks: Sequence[np.ndarray], starts: Sequence[int], n_samples: int, win: int) -> np.ndarray:
-    """Overlap-add average of per-chunk frame scores [frames, C] onto one global frame grid."""
-    C = chunks[0].shape[1]
-    n_out = int(np.ceil(n_samples / 270)) + 1
-    acc = np.zeros((n_out, C), dtype=np.float64)
-    cnt = np.zeros((n_out, 1), dtype=np.float64)
-    for sc, s0 in zip(chunks, starts):
-        f0 = int(round(s0 / 270))
-        f1 = min(n_out, f0 + sc.shape[0])
-        acc[f0:f1] += sc[: f1 - f0]
-        cnt[f0:f1] += 1
-    return (acc / np.maximum(cnt, 1)).astype(np.float32)
+def n_frames_out(n_chunks: int, win: int, step: int) -> int:
+    """Length of the global frame grid of `n_chunks` windows (Inference.aggregate: closest frame of the last window's end, + 1)."""
+    return int(np.rint((win + (n_chunks - 1) * step) / 270.0)) + 1
 
 
-def aggregate_cm(cm: np.ndarray, starts: Sequence[int], n_samples: int) -> np.ndarray:
-    """`aggregate` for equal-sized windows held class-major: cm [C, windows, frames] -> [n_out, C].  Same accumulation
-    order and precision as `aggregate`; the class axis is outermost so every slice added is contiguous (reductions
-    and slices along a trailing axis of 3 or 7 entries are what numpy is slowest at)."""
-    C, _, F = cm.shape
-    n_out = int(np.ceil(n_samples / 270)) + 1
-    acc = np.zeros((C, n_out), dtype=np.float64)
-    cnt = np.zeros(n_out, dtype=np.float64)
+def aggregate(chunks: Sequence[np.ndarray], starts: Sequence[int], win: int, step: int, hamming: bool = False,
+              average: bool = True) -> np.ndarray:
+    """Overlap-add of per-chunk frame scores [frames, C] onto one global frame grid (Inference.aggregate, warm-up 0): flat or
+    Hamming-weighted, averaged or summed; float32 accumulators in window order, frames no window covers are 0."""
+    return aggregate_cm(np.ascontiguousarray(np.moveaxis(np.stack(chunks), -1, 0)), starts, win, step, hamming, average)
+
+
+def aggregate_cm(cm: np.ndarray, starts: Sequence[int], win: int, step: int, hamming: bool = False, average: bool = True) -> np.ndarray:
+    """`aggregate` for equal-sized windows held class-major: cm [C, windows, frames] -> [n_out, C].  The class axis is
+    outermost so every slice added is contiguous (reductions and slices along a trailing axis of 3 or 7 entries are what
+    numpy is slowest at)."""
+    C, W, F = cm.shape
+    n_out = n_frames_out(W, win, step)
+    wgt = (np.hamming(F) if hamming else np.ones(F)).astype(np.float32)
+    acc = np.zeros((C, n_out), dtype=np.float32)
+    cnt = np.zeros(n_out, dtype=np.float32)
+    cmw = cm.astype(np.float32, copy=False) * wgt if hamming else cm.astype(np.float32, copy=False)
     for w, s0 in enumerate(starts):
-        f0 = int(round(s0 / 270))
-        f1 = min(n_out, f0 + F)
-        acc[:, f0:f1] += cm[:, w, : f1 - f0]
-        cnt[f0:f1] += 1
-    return np.ascontiguousarray((acc / np.maximum(cnt, 1)).T.astype(np.float32))
+        f0 = int(np.rint(s0 / 270.0))
+        acc[:, f0:f0 + F] += cmw[:, w]
+        cnt[f0:f0 + F] += wgt
+    if average:
+        acc = acc / np.maximum(cnt, np.float32(1e-12))
+    return np.ascontiguousarray(acc.T)
 
 
 def _powerset_table(n_spk: int = 3, max_set: int = 2) -> np.ndarray:
@@ -183,13 +185,14 @@ def binarize(score: np.ndarray, onset: float, offset: float, min_on: float = 0.0
                 start, active = float(t), True
         if active:
             regions.append((start, float(times[-1])))
+    regions = [(s, e) for s, e in regions if e - s > 1e-6]            # an empty segment never enters an Annotation
     merged: List[Tuple[float, float]] = []
     for s, e in regions:
-        if merged and s - merged[-1][1] < min_off:
+        if min_off > 0.0 and merged and s - merged[-1][1] < min_off:   # Timeline.support(collar): gaps shorter than the collar
             merged[-1] = (merged[-1][0], e)
         else:
             merged.append((s, e))
-    return [(s, e) for s, e in merged if e - s >= min_on and e > s]
+    return [(s, e) for s, e in merged if e - s >= min_on]
 
 
 class VoiceActivityDetection:
@@ -213,21 +216,16 @@ class VoiceActivityDetection:
             crops.append(c)
         return starts, crops
 
-    def _score(self, outs, starts, n):
-        if len({o.shape for o in outs}) == 1:
-            outs = np.stack(outs)               # equal windows: class-major, one contiguous add per window
-            if self.net.powerset:
-                sc = 1.0 - np.exp(outs[..., 0])
-            else:
-                sc = outs[..., 0]
-                for c in range(1, outs.shape[-1]):
-                    sc = np.maximum(sc, outs[..., c])
-            return aggregate_cm(sc[None], starts, n)[:, 0]
-        if self.net.powerset:   # a powerset model used as VAD: speech = 1 - P(empty set)
-            sc = [1.0 - np.exp(o[:, :1]) for o in outs]
+    def _score(self, outs, starts):
+        """Pre-aggregation hook (max over the speakers) + Hamming-weighted overlap-add average (Inference.slide)."""
+        outs = np.stack(outs)                   # equal windows: class-major, one contiguous add per window
+        if self.net.powerset:                   # a powerset model is decoded to hard multi-label first (Inference's conversion)
+            sc = multilabel_cm(outs, True).max(axis=0)
         else:
-            sc = [o.max(axis=-1, keepdims=True) for o in outs]
-        return aggregate(sc, starts, n, self.win)[:, 0]
+            sc = outs[..., 0]
+            for c in range(1, outs.shape[-1]):
+                sc = np.maximum(sc, outs[..., c])
+        return aggregate_cm(sc[None], starts, self.win, self.step, hamming=True)[:, 0]
 
     def begin(self, items: Sequence):
         """Cut the windows of all items and QUEUE the network; returns a handle for `finish`.  Nothing waits for the GPU
@@ -252,11 +250,10 @@ class VoiceActivityDetection:
                 anns.append(Annotation([]))
                 continue
             starts, i0, n = pl
-            score = self._score(outs[i0:i0 + n], starts, len(x))
-            n_valid = min(len(score), int(len(x) / 270))
-            regions = binarize(score[:n_valid], self.onset, self.offset, self.min_on, self.min_off)
-            dur = len(x) / SR
-            anns.append(Annotation([(max(0.0, s), min(dur, e), "SPEECH") for s, e in regions if min(dur, e) > max(0.0, s)]))
+            score = self._score(outs[i0:i0 + n], starts)
+            n_valid = min(len(score), int(np.floor((len(x) / SR) / FRAME_STEP)) + 1)   # crop(Segment(0, duration), mode="loose")
+            on, off = (0.5, 0.5) if self.net.powerset else (self.onset, self.offset)
+            anns.append(Annotation([(s, e, "SPEECH") for s, e in binarize(score[:n_valid], on, off, self.min_on, self.min_off)]))
         return anns
 
     def batch(self, items: Sequence) -> List[Annotation]:
@@ -267,48 +264,84 @@ class VoiceActivityDetection:
         return self.batch([path_or_wave])[0]
 
 
-def agglomerative_centroid(emb: np.ndarray, threshold: float, min_cluster_size: int, min_clusters: int, max_clusters: int) -> np.ndarray:
-    """pyannote AgglomerativeClustering (centroid linkage on unit-normalised embeddings, euclidean): cut at
-    `threshold`, keep clusters with >= min_cluster_size members as "large", re-assign the rest to the nearest
-    large centroid, then force the number of clusters into [min_clusters, max_clusters]."""
+def _large_clusters(lab: np.ndarray, min_size: int):
+    ids, sizes = np.unique(lab, return_counts=True)
+    return ids, sizes, ids[sizes >= min_size]
+
+
+def agglomerative_centroid(emb: np.ndarray, threshold: float, min_cluster_size: int, min_clusters: int, max_clusters: int,
+                           num_clusters: Optional[int] = None) -> np.ndarray:
+    """pyannote AgglomerativeClustering.cluster (centroid linkage on unit-normalised embeddings, euclidean): cut the dendrogram at
+    `threshold`; clusters of >= min(min_cluster_size, max(1, round(n / 10))) members are "large".  When the number of large
+    clusters falls outside [min_clusters, max_clusters] (or `num_clusters` is given) the cut moves to the merge, closest in
+    distance to the threshold, that yields the wanted number of large clusters.  Small clusters join the large cluster with the
+    nearest centroid (cosine); labels are renumbered 0 .. k-1 in the order of scipy's flat-cluster ids."""
     from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.spatial.distance import cdist
     n = emb.shape[0]
     if n == 1:
         return np.zeros(1, dtype=np.int64)
-    e = emb / np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-12)
+    big = min(min_cluster_size, max(1, round(0.1 * n)))
+    e = np.asarray(emb, dtype=np.float64)
+    e = e / np.linalg.norm(e, axis=-1, keepdims=True)
     Z = linkage(e, method="centroid", metric="euclidean")
     lab = fcluster(Z, threshold, criterion="distance") - 1
-    sizes = np.bincount(lab)
-    big = min(min_cluster_size, max(1, n // 4))
-    large = [c for c in range(len(sizes)) if sizes[c] >= big]
-    if not large:
-        large = [int(np.argmax(sizes))]
-    if len(large) > max_clusters:
-        large = sorted(large, key=lambda c: -sizes[c])[:max_clusters]
-    elif len(large) < min_clusters:
-        # centroid linkage is not monotonic, so "maxclust = k" may return fewer than k clusters: grow the
-        # request until at least min_clusters come out, then keep the min_clusters largest
-        for m in range(min_clusters, n + 1):
-            lab = fcluster(Z, m, criterion="maxclust") - 1
-            sizes = np.bincount(lab)
-            if np.count_nonzero(sizes) >= min(min_clusters, n):
+    ids, sizes, large = _large_clusters(lab, big)
+    if len(large) < min_clusters:
+        num_clusters = min_clusters
+    elif len(large) > max_clusters:
+        num_clusters = max_clusters
+    if num_clusters is not None:
+        Zi = Z.copy()
+        Zi[:, 2] = np.arange(n - 1)                     # cut by merge index instead of by distance
+        best_it, best_n = n - 1 - num_clusters, len(large)
+        for it in np.argsort(np.abs(Z[:, 2] - threshold)):
+            if Zi[it, 3] < big:                          # this merge cannot have changed the number of large clusters
+                continue
+            lab = fcluster(Zi, it, criterion="distance") - 1
+            ids, sizes, large = _large_clusters(lab, big)
+            if abs(len(large) - num_clusters) < abs(best_n - num_clusters):
+                best_it, best_n = it, len(large)
+            if len(large) == num_clusters:
                 break
-        large = sorted([c for c in range(len(sizes)) if sizes[c] > 0], key=lambda c: -sizes[c])[:min_clusters]
-    cents = np.stack([e[lab == c].mean(axis=0) for c in large])
-    d = ((e[:, None, :] - cents[None, :, :]) ** 2).sum(-1)
-    return np.argmin(d, axis=1).astype(np.int64)
+        if best_n != num_clusters:
+            lab = fcluster(Zi, best_it, criterion="distance") - 1
+            ids, sizes, large = _large_clusters(lab, big)
+    if len(large) == 0:
+        return np.zeros(n, dtype=np.int64)
+    small = ids[sizes < big]
+    if len(small):
+        cl = np.vstack([e[lab == k].mean(axis=0) for k in large])
+        cs = np.vstack([e[lab == k].mean(axis=0) for k in small])
+        for j, k in enumerate(np.argmin(cdist(cl, cs, metric="cosine"), axis=0)):
+            lab[lab == small[j]] = large[k]
+        lab = np.unique(lab, return_inverse=True)[1]
+    return lab.astype(np.int64)
+
+
+def assign_to_centroids(embs: np.ndarray, train_rows: np.ndarray, train_labels: np.ndarray) -> np.ndarray:
+    """BaseClustering.assign_embeddings (unconstrained): centroid k = mean of the training embeddings of cluster k; every
+    embedding -- training or not -- goes to the centroid with the largest cosine similarity (a NaN row goes to 0)."""
+    from scipy.spatial.distance import cdist
+    e = np.asarray(embs, dtype=np.float64)
+    cents = np.vstack([e[train_rows][train_labels == k].mean(axis=0) for k in range(int(train_labels.max()) + 1)])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.argmax(2.0 - cdist(e, cents, metric="cosine"), axis=1).astype(np.int64)
 
 
 class SpeakerDiarization:
-    """pyannote/speaker-diarization-3.1 shape: powerset segmentation over 10 s windows (10 % step), one
-    embedding per (window, local speaker) from overlap-free frames, agglomerative clustering, per-frame
-    speaker count x clustered activations -> timeline."""
+    """pyannote/speaker-diarization-3.1: powerset segmentation over 10 s windows (10 % step) decoded to hard multi-label, one
+    embedding per ACTIVE (window, local speaker) pooled over its overlap-free frames when more than `min_num_frames` remain,
+    agglomerative clustering of the finite embeddings + nearest-centroid assignment of all of them, per-frame speaker count
+    (rounded overlap-add average) x summed clustered activations -> top-`count` clusters per frame -> timeline.
+    `min_num_frames` = ceil(589 * min_num_samples / 160000) with the embedding model's shortest usable input (one 25 ms
+    fbank frame for the ResNet-34, recalled) = 2."""
 
     def __init__(self, seg_net, embedder, duration: float = 10.0, step_ratio: float = 0.1, threshold: float = 0.7045654963945799,
-                 min_cluster_size: int = 12, min_duration_off: float = 0.0, min_active_ratio: float = 0.2, batch: int = 32):
+                 min_cluster_size: int = 12, min_duration_off: float = 0.0, min_num_frames: int = 2, batch: int = 32):
         self.net, self.emb = seg_net, embedder
         self.win, self.step = int(duration * SR), int(duration * step_ratio * SR)
-        self.threshold, self.min_cluster_size, self.min_off, self.min_active, self.batch_size = threshold, min_cluster_size, min_duration_off, min_active_ratio, batch
+        self.threshold, self.min_cluster_size, self.min_off, self.min_num_frames, self.batch_size = threshold, min_cluster_size, min_duration_off, min_num_frames, batch
 
     def __call__(self, path_or_wave, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
                  num_speakers: Optional[int] = None) -> Annotation:
@@ -357,12 +390,10 @@ class SpeakerDiarization:
             arr = np.stack(seg[i0:i0 + n])                                   # [windows, frames, classes]: windows are equal-sized
             mc = multilabel_cm(arr, self.net.powerset)                       # [speakers, windows, frames] float32 0/1
             n_spk = mc.sum(axis=0)                                           # active speakers per frame
-            alone = n_spk == 1
-            cleanf = mc * alone                                              # overlap-free activity
+            cleanf = mc * (n_spk < 2)                                        # overlap-free activity
             n_act, n_clean = mc.sum(axis=-1), cleanf.sum(axis=-1)            # [speakers, windows] frame counts (exact in fp32)
-            keep = n_act.astype(np.float64) / mc.shape[-1] >= self.min_active  # local speakers active for >= min_active_ratio
-            use_clean = n_clean >= 0.5 * n_act                               # prefer overlap-free frames when enough remain
-            kw, ks = np.nonzero(keep.T)                                      # row-major: window, then speaker
+            use_clean = n_clean > self.min_num_frames                        # prefer overlap-free frames when enough remain
+            kw, ks = np.nonzero((n_act > 0).T)                               # every ACTIVE local speaker; row-major: window, then speaker
             keys = list(zip(kw.tolist(), ks.tolist()))
             e_crops += (i0 + kw).tolist()
             if len(keys):
@@ -381,8 +412,8 @@ class SpeakerDiarization:
 
     def finish(self, handle, min_speakers: Optional[int] = None, max_speakers: Optional[int] = None,
                num_speakers: Optional[int] = None) -> List[Annotation]:
-        lo = num_speakers or min_speakers or 1
-        hi = num_speakers or max_speakers or 20
+        lo = num_speakers or min_speakers or 1                               # set_num_speakers
+        hi = num_speakers or max_speakers or None
         xs, per_item, embs = handle
         embs = np.zeros((0, getattr(self.emb, "DIM", 512)), dtype=np.float32) if embs is None else embs.cpu().numpy()
         anns, e0 = [], 0
@@ -391,43 +422,46 @@ class SpeakerDiarization:
                 anns.append(Annotation([]))
                 continue
             starts, mc, keys, n_spk = it
-            anns.append(self._reconstruct(len(x), starts, mc, keys, embs[e0:e0 + len(keys)], lo, hi, n_spk))
+            anns.append(self._reconstruct(starts, mc, keys, embs[e0:e0 + len(keys)], num_speakers, lo, hi, n_spk))
             e0 += len(keys)
         return anns
 
-    def _reconstruct(self, n_samples: int, starts, mc, keys, embs, lo: int, hi: int, n_spk=None) -> Annotation:
-        """mc: hard local activity [speakers, windows, frames]; keys: the (window, local speaker) pairs that were embedded."""
-        dur = n_samples / SR
+    def _cluster(self, embs: np.ndarray, num: Optional[int], lo: int, hi: Optional[int]) -> np.ndarray:
+        """BaseClustering.__call__ over the embeddings of the active local speakers: cluster the finite ones, assign all."""
+        ok = np.flatnonzero(np.isfinite(embs).all(axis=1))
+        n = len(ok)
+        lo_c = max(1, min(n, num or lo or 1))                                # set_num_clusters
+        hi_c = max(1, min(n, num or hi or n))
+        if lo_c > hi_c:
+            raise ValueError("min_speakers must not exceed max_speakers")
+        if lo_c == hi_c:
+            num = lo_c
+        if hi_c < 2:
+            return np.zeros(len(embs), dtype=np.int64)
+        train = agglomerative_centroid(embs[ok], self.threshold, self.min_cluster_size, lo_c, hi_c, num)
+        return assign_to_centroids(embs, ok, train)
+
+    def _reconstruct(self, starts, mc, keys, embs, num: Optional[int], lo: int, hi: Optional[int], n_spk=None) -> Annotation:
+        """mc: hard local activity [speakers, windows, frames]; keys: the ACTIVE (window, local speaker) pairs, embs their embeddings."""
         if n_spk is None:
             n_spk = mc.sum(axis=0)
-        count = np.rint(aggregate_cm(n_spk[None], starts, n_samples)[:, 0]).astype(np.int64)
-        count = np.minimum(count, hi)
-        ok = np.isfinite(embs).all(axis=1)
-        labels = np.full(len(keys), -1, dtype=np.int64)
-        if ok.any():
-            labels[ok] = agglomerative_centroid(embs[ok], self.threshold, self.min_cluster_size, lo, hi)
-        n_clusters = int(labels.max()) + 1
-        if n_clusters <= 0:
+        count = np.rint(aggregate_cm(n_spk[None], starts, self.win, self.step)[:, 0]).astype(np.int64)      # speaker_count
+        if count.max() == 0:
             return Annotation([])
-        clustered = np.zeros((n_clusters,) + mc.shape[1:], dtype=np.float32)
-        for (kc, sp), lab in zip(keys, labels):                            # one pass over the (window, local speaker) keys
-            if lab >= 0:
-                np.maximum(clustered[lab, kc], mc[sp, kc], out=clustered[lab, kc])
-        agg = aggregate_cm(clustered, starts, n_samples)                   # [frames, clusters]
-        n_valid = min(agg.shape[0], int(n_samples / 270))
-        agg, count = agg[:n_valid], count[:n_valid]
-        # to_diarization: at each frame the `count` most active clusters speak
-        order = np.argsort(-agg, axis=1)
-        ranks = np.argsort(order, axis=1)                                  # rank of every cluster at every frame
-        binary = ((ranks < count[:, None]) & (agg > 0)).astype(np.float32)
+        labels = self._cluster(embs, num, lo, hi)
+        if hi is not None:
+            count = np.minimum(count, hi)
+        n_clusters = int(labels.max()) + 1
+        clustered = np.zeros((max(n_clusters, int(count.max())),) + mc.shape[1:], dtype=np.float32)
+        for (kc, sp), lab in zip(keys, labels):                            # max over the local speakers of a cluster, per window
+            np.maximum(clustered[lab, kc], mc[sp, kc], out=clustered[lab, kc])
+        act = aggregate_cm(clustered, starts, self.win, self.step, average=False)                           # [frames, clusters]
+        # to_diarization: at each frame the `count` most active clusters speak (stable order on ties)
+        ranks = np.argsort(np.argsort(-act, axis=1, kind="stable"), axis=1, kind="stable")
+        binary = (ranks < count[:, None]).astype(np.float32)
         tracks = []
-        first_seen = {}
-        for c in range(n_clusters):
-            regs = binarize(binary[:, c], 0.5, 0.5, 0.0, self.min_off)
-            for s, e in regs:
-                s, e = max(0.0, s - 0.5 * FRAME_STEP), min(dur, e + 0.5 * FRAME_STEP)
-                if e > s:
-                    tracks.append((s, e, c))
-                    first_seen[c] = min(first_seen.get(c, 1e9), s)
-        rename = {c: f"SPEAKER_{i:02d}" for i, c in enumerate(sorted(first_seen, key=lambda c: first_seen[c]))}
+        for c in range(binary.shape[1]):
+            tracks += [(s, e, c) for s, e in binarize(binary[:, c], 0.5, 0.5, 0.0, self.min_off)]
+        present = sorted({c for _, _, c in tracks})                        # labels() in sorted order take SPEAKER_00, SPEAKER_01, ...
+        rename = {c: f"SPEAKER_{i:02d}" for i, c in enumerate(present)}
         return Annotation([(s, e, rename[c]) for s, e, c in tracks])

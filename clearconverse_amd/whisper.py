@@ -138,6 +138,10 @@ class WhisperModel:
         sp = int((stream or torch.cuda.current_stream()).cuda_stream)
         self.ctx.check(self.lib.ccx_whisper_prepare_lanes(self.handle, sp), "ccx_whisper_prepare_lanes")
 
+    def trace_lanes(self, path: Optional[str], level: int = 1):
+        """Switch the in-graph lane trace on (path) or off (None): ccx_whisper_trace_lanes.  Drops the captured step graphs."""
+        self.ctx.check(self.lib.ccx_whisper_trace_lanes(self.handle, path.encode() if path else None, int(level)), "ccx_whisper_trace_lanes")
+
     def decode_greedy(self, prompts: Sequence[Sequence[int]], sample_len: Optional[int] = None) -> List[dict]:
         """Greedy DecodingTask.run over the currently encoded windows (temperature 0)."""
         return self.decode(prompts, sample_len, temperature=0.0)

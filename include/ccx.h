@@ -106,9 +106,11 @@ int ccx_whisper_set_tensor(ccx_whisper* w, const char* name, const void* data, i
  * whole clip is normalised with its global maximum, exactly like whisper.audio.log_mel_spectrogram. */
 int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds);
 /* Optional, before finalize: take the log-mel / encoder workspaces of `donor` (finalized, same dimensions, at least this
- * instance's capacity) instead of allocating them.  They are only live between ccx_whisper_logmel and the end of
- * ccx_whisper_encode, so this is safe exactly when the two instances' log-mel / encode calls are ordered on one stream (the
- * software-pipelined batch driver: one instance decodes while the other encodes).  The donor must outlive the taker. */
+ * instance's capacity) instead of allocating them.  They are only live between ccx_whisper_logmel / set_mel and the end of
+ * ccx_whisper_encode.  Users of one group are ordered by the library: every logmel / set_mel waits (event) for the end of the
+ * group's previous encode, on whatever streams they run -- so an instance may encode while ANOTHER instance of the group decodes
+ * (the software-pipelined batch driver), but the host must issue logmel .. encode of one instance before the next instance's
+ * logmel.  A donor destroyed while takers are alive is freed when its last taker is destroyed. */
 int ccx_whisper_share_encoder_scratch(ccx_whisper* w, ccx_whisper* donor);
 /* Checks every tensor is present, builds the fused/bf16 device layouts, uploads. */
 int ccx_whisper_finalize(ccx_whisper* w);
@@ -154,6 +156,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
  * queues; the choice is made by a short timing probe, which must not be disturbed by other work on the GPU).  Call it on an
  * otherwise idle device before decodes are overlapped with other streams; ccx_whisper_decode does it lazily otherwise. */
 int ccx_whisper_prepare_lanes(ccx_whisper* w, void* stream);
+/* Measurement helper (no counterpart in the reference): while `path` is non-NULL every hipGraph-captured decode step carries
+ * one-thread stamp kernels (100 MHz s_memrealtime) around the cross attention of every layer (level 1) or after every kernel of
+ * the chain (level 2), per decode lane; each ccx_whisper_decode appends its trace to `path` ("decode B <n> lanes <l>" + one line
+ * per lane; tools/decode_stamps.py, bench.py `roofline.frac_in_situ`).  NULL switches it off.  Either call drops the captured
+ * step graphs.  Equivalent to creating the model with CCX_DEC_STAMPS=<path> in the environment. */
+int ccx_whisper_trace_lanes(ccx_whisper* w, const char* path, int level);
 
 /* ---- RE-SepFormer separator (replaces self.separator, reference back/api.py:713-717; call at
  *      back/api.py:1077 `separated = self.separator.separate_batch(subsegment)`) -------------------- */

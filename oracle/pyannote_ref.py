@@ -116,9 +116,11 @@ def xvector_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, weights: Opt
     return F.linear(pooled, sd["embedding.weight"].float(), sd["embedding.bias"].float())[0]
 
 
-def pyannet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, n_lstm: int = 4, hidden: int = 128) -> torch.Tensor:
+def pyannet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, n_lstm: int = 4, hidden: int = 128,
+                    return_features: bool = False) -> torch.Tensor:
     """PyanNet.forward: wav [B, 1, T] -> per-frame class scores [B, frames, C] (log-softmax for the
-    powerset model, sigmoid for the multi-label one -- chosen by `sd['activation']`)."""
+    powerset model, sigmoid for the multi-label one -- chosen by `sd['activation']`).  `return_features`: the input of the
+    classifier [B, frames, 128] instead (used by tests/scripted_nets.py to fit a scripted classifier)."""
     x = sincnet_forward(sd, wav)                # [B, 60, F]
     x = x.permute(0, 2, 1)                      # [B, F, 60]
     B = x.shape[0]
@@ -144,6 +146,8 @@ def pyannet_forward(sd: Dict[str, torch.Tensor], wav: torch.Tensor, n_lstm: int 
         x = torch.cat(outs, dim=-1)
     for i in range(2):
         x = F.leaky_relu(F.linear(x, sd[f"linear.{i}.weight"].float(), sd[f"linear.{i}.bias"].float()))
+    if return_features:
+        return x
     x = F.linear(x, sd["classifier.weight"].float(), sd["classifier.bias"].float())
     if int(sd.get("powerset", torch.tensor(1))) == 1:
         return F.log_softmax(x, dim=-1)

@@ -49,6 +49,26 @@ class FakeEmb:
         return torch.from_numpy(out)
 
 
+class ContentEmb:
+    """An embedder whose output depends only on the pooling mask (not on the row's position in a batch), so that the product
+    (embeds the active pairs, batched) and the oracle (embeds every pair, one call each) see the same vectors: `n_voices`
+    well separated directions picked by the mask's frame count, plus small seeded noise; an all-zero mask gives NaN."""
+    DIM = 32
+
+    def __init__(self, n_voices=3, seed=5):
+        self.dirs = np.random.default_rng(seed).standard_normal((n_voices, self.DIM)).astype(np.float32) * 3.0
+
+    def emb_fn(self, chunk, mask):
+        n = int(np.asarray(mask).sum())
+        if n == 0:
+            return np.full(self.DIM, np.nan, dtype=np.float32)
+        first = int(np.flatnonzero(np.asarray(mask) > 0)[0])
+        return (self.dirs[(n // 7) % len(self.dirs)] + 0.3 * np.random.default_rng(n * 1000 + first).standard_normal(self.DIM)).astype(np.float32)
+
+    def embed_chunks(self, chunks, weights, mask_chunk):
+        return torch.from_numpy(np.stack([self.emb_fn(None, w) for w in weights.numpy()]))
+
+
 def run(n_items=4):
     from clearconverse_amd import pipelines as P
     items = [{"waveform": torch.from_numpy(np.random.default_rng(i).standard_normal(480000 - 7000 * (i % 3)).astype(np.float32)),

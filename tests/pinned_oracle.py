@@ -102,3 +102,64 @@ def whisper_check(orc: R.WhisperRef, orules: R.Rules, wave: np.ndarray, prompt: 
             decisive += 1
         seq.append(t); sampled.append(t)
     return len(forced), decisive
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# A13 / A14: the two pyannote pipelines on the RAW clip (reference back/api.py:1311-1312 VAD, 1052-1064 diarization with
+# min_speakers=1 / max_speakers=2), oracle networks -> oracle post-net (oracle/pyannote_pipeline_ref.py).
+def oracle_seg_fn(sd: Dict[str, torch.Tensor], powerset: bool):
+    osd = dict(sd)
+    osd["powerset"] = torch.tensor(1 if powerset else 0)
+
+    def fn(chunks: List[np.ndarray]) -> List[np.ndarray]:
+        with torch.no_grad():
+            return list(P.pyannet_forward(osd, torch.from_numpy(np.stack(chunks))[:, None]).numpy())
+    return fn
+
+
+def oracle_emb_fn(rsd: Dict[str, torch.Tensor]):
+    """emb_fn(chunk, mask) on the oracle ResNet-34; the trunk of a chunk is computed once and reused for its masks."""
+    from oracle import wespeaker_ref as W
+    cache: Dict[bytes, torch.Tensor] = {}
+
+    def fn(chunk: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        key = chunk[:4096].tobytes() + chunk[-4096:].tobytes()
+        with torch.no_grad():
+            if key not in cache:
+                cache.clear()
+                cache[key] = W.resnet_trunk(rsd, torch.from_numpy(W.compute_fbank(chunk))[None])
+            pooled = W.stats_pool(cache[key], torch.from_numpy(np.asarray(mask, dtype=np.float32))[None])
+            return torch.nn.functional.linear(pooled, rsd["resnet.seg_1.weight"].float(), rsd["resnet.seg_1.bias"].float())[0].numpy()
+    return fn
+
+
+def run_pipelines(clip: np.ndarray, sds: Dict[str, object], **speakers) -> dict:
+    from oracle import pyannote_pipeline_ref as O
+    vp, dp = sds.get("vad_params") or {}, sds.get("diarization_params") or {}
+    vad = O.voice_activity_detection(clip, oracle_seg_fn(sds["pyannet_vad"], False), False,
+                                     **{k: vp[k] for k in ("onset", "offset", "min_duration_on", "min_duration_off") if k in vp})
+    kw = {k: dp[k] for k in ("threshold", "min_cluster_size", "min_duration_off") if k in dp}
+    diar = O.speaker_diarization(clip, oracle_seg_fn(sds["pyannet_diar"], True), oracle_emb_fn(sds["resnet34"]), **speakers, **kw)
+    return dict(vad=vad, diarization=sorted(diar, key=lambda t: (t[0], t[1])))
+
+
+def timeline_agreement(a, b, duration: float, step: float = 0.005) -> float:
+    """Fraction of (time cell, label) decisions on which two labelled timelines [(start, end, label)] agree, under the best
+    one-to-one label mapping (labels are arbitrary strings: reference back/api.py:1330-1352 maps them by first appearance)."""
+    import itertools
+    n = int(np.ceil(duration / step))
+    la, lb = sorted({l for *_, l in a}), sorted({l for *_, l in b})
+
+    def raster(tl, labels):
+        m = np.zeros((max(1, len(labels)), n), dtype=bool)
+        for s, e, l in tl:
+            m[labels.index(l), max(0, int(round(s / step))):min(n, int(round(e / step)))] = True
+        return m
+    ma, mb = raster(a, la), raster(b, lb)
+    k = max(ma.shape[0], mb.shape[0])
+    ma = np.concatenate([ma, np.zeros((k - ma.shape[0], n), dtype=bool)])
+    mb = np.concatenate([mb, np.zeros((k - mb.shape[0], n), dtype=bool)])
+    best = 0.0
+    for perm in itertools.permutations(range(k)):
+        best = max(best, float((ma == mb[list(perm)]).mean()))
+    return best

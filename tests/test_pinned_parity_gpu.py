@@ -36,8 +36,13 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
     from oracle import whisper_ref as R
     from tests import pinned_oracle as O
 
+    from tests.scripted_nets import scripted_pyannet_state_dict
     wd, sdims = WhisperDims.mini(2, 128), SepDims(n_layers=2)
     sds = build_state_dicts(None, whisper_dims=wd, sep_dims=sdims, seed=7)
+    # scripted segmentation weights (fitted to clip 40's schedule; clip 41 gets whatever they give on it): with seeded random
+    # weights both pipelines return one constant class and their comparison below would be vacuous
+    sds["pyannet_diar"], _ = scripted_pyannet_state_dict(40, 7, True)
+    sds["pyannet_vad"], _ = scripted_pyannet_state_dict(40, 3, False, window_s=5.0, seed=4)
     models = load_models(None, 0, whisper_batch=16, ctx=ccx_ctx, state_dicts=sds, sep_tokens=60_000, max_crops=128)
     sample_len = 6
     bp = BatchPipeline(models, whisper_group=16, sample_len=sample_len)
@@ -55,6 +60,17 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
         worst[name] = max(worst.get(name, 0.0), float(v))
 
     for b, clip in enumerate(clips):
+        # A14 / A13 (reference back/api.py:1311-1312, 1052-1064): the VAD and diarization the pinned pipeline computes on the raw
+        # clip against oracle networks -> oracle post-net.  Same region count and boundaries within one frame for the VAD; the
+        # diarization timelines agree on >= 97 % of the (time, speaker) cells up to a label permutation (tests/test_pipelines_gpu.py
+        # explains the tolerance and checks the post-net bit for bit on the GPU's own network outputs)
+        po = O.run_pipelines(clip, sds, min_speakers=1, max_speakers=2)
+        assert len(r["vad"][b]) == len(po["vad"]) >= 1, (b, r["vad"][b], po["vad"])
+        dev = max(max(abs(x[0] - y[0]), abs(x[1] - y[1])) for x, y in zip(r["vad"][b], po["vad"]))
+        assert dev <= 270 / 16000 + 1e-9, (b, dev)
+        agree = O.timeline_agreement(r["diarization"][b], po["diarization"], 40.0)
+        track("vad_boundary_s", dev); track("diarization_disagreement", 1.0 - agree)
+        assert agree >= 0.97 and len(r["diarization"][b]) >= 2, (b, agree)
         o = O.run_clip(clip, sds, sdims)
         track("den", _rel(r["den"][b], o["den"]))
         assert _rel(r["den"][b], o["den"]) < 1e-5
@@ -176,3 +192,110 @@ def test_configs3_full_size_clip_records_do_not_depend_on_batch_mates(ccx_ctx):
             assert abs(one["records"][j]["sum_logprob"] - lp) < 2e-3 * max(1.0, abs(lp)), (b, j)
     for m in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
         models[m].close()
+
+
+def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(ccx_ctx):
+    """The configuration bench.py TIMES by default, at full size: four batches of 32 x 30 s clips through
+    `run_pinned_pipelined(span=4)` -- ONE 768-sequence decode group in two hipGraph lanes of 384 rows, two Whisper instances of
+    768 windows sharing their log-mel / encoder workspaces (`ccx_whisper_share_encoder_scratch`), full small.en, full-depth
+    SepFormer (load_models exactly as bench.py calls it) -- with a short sample_len.  Clips are independent units (reference
+    back/api.py:1298), so (a) every batch must equal `run_pinned` of that batch alone (192-sequence groups in three lanes of 64):
+    identical tokens, prompts, source picks, similarities, embeddings and separated waveforms bit for bit; log-probabilities
+    bit for bit too if the lane width does not enter the arithmetic (reported), else to 2e-3 relative; (b) clips 0, 13 and 31 of
+    batch 2, run alone (6 sequences, small-batch decode path), give the same tokens, bit-identical embeddings / separated
+    waveforms and log-probabilities to 2e-3 relative (6 split-KV partials instead of one block per key range)."""
+    from clearconverse_amd.batch import BatchPipeline
+    from clearconverse_amd.models import build_state_dicts, load_models
+    B, sample_len, span = 32, 4, 4
+    group = 6 * B * span
+    sds = build_state_dicts(None, seed=0)
+    assert sds["whisper_dims"]["n_audio_layer"] == 12 and sds["sep_dims"]["n_layers"] == 8      # full size
+    models = load_models(None, 0, whisper_batch=group, ctx=ccx_ctx, seed=0, state_dicts=sds, seg_max_crops=52 * B + 16,
+                         seg_max_seconds=300.0 * B, emb_max_crops=44 * B, resnet_max_chunks=21 * B, whisper_instances=2,
+                         max_audio_seconds=30.0, gate_max_clips=B)
+    del sds
+    try:
+        bp = BatchPipeline(models, whisper_group=group, sample_len=sample_len)
+        batches = [torch.from_numpy(np.stack([synthetic_clip(100 * k + i, 30.0) for i in range(B)])).cuda().contiguous() for k in range(span)]
+        seq = [bp.run_pinned(a, debug=True) for a in batches]
+        pip = bp.run_pinned_pipelined(batches, debug=True, span=span)
+        pip2 = bp.run_pinned_pipelined(batches, debug=True, span=span)          # second pass: replays the captured 384-row lane graphs
+        assert len(pip) == len(pip2) == span
+        lp_bits = True
+        for k, (a, b, c) in enumerate(zip(seq, pip, pip2)):
+            assert a["whisper_calls"] == b["whisper_calls"] == 6 * B and len(b["records"]) == 6 * B
+            assert [r["tokens"] for r in a["records"]] == [r["tokens"] for r in b["records"]] == [r["tokens"] for r in c["records"]], k
+            assert all(len(r["tokens"]) > 0 for r in b["records"])
+            assert [r["sum_logprob"] for r in b["records"]] == [r["sum_logprob"] for r in c["records"]], k       # replay == capture pass
+            for x, y in zip(a["records"], b["records"]):
+                lp_bits &= x["sum_logprob"] == y["sum_logprob"]
+                assert abs(x["sum_logprob"] - y["sum_logprob"]) <= 2e-3 * max(1.0, abs(x["sum_logprob"])), k
+                assert abs(x["no_speech_prob"] - y["no_speech_prob"]) <= 1e-4, k
+            assert a["sims"] == b["sims"] and a["pick"] == b["pick"] and a["prompt_ids"] == b["prompt_ids"], k
+            assert torch.equal(a["window_sims_full"], b["window_sims_full"]) and torch.equal(a["separated"], b["separated"]), k
+            assert torch.equal(a["profile_embeds"], b["profile_embeds"]) and torch.equal(a["den"], b["den"]), k
+            assert a["vad"] == b["vad"] and a["diarization"] == b["diarization"], k
+        print("span-4 pipelined (2 x 384-row lanes) vs sequential (3 x 64-row lanes): log-probabilities",
+              "bit-identical" if lp_bits else "equal to 2e-3 relative (not bit-identical)")
+        full = pip[2]
+        for bsel in (0, 13, 31):
+            one = bp.run_pinned(batches[2][bsel:bsel + 1].contiguous(), debug=True)
+            assert np.allclose(one["sims"], full["sims"][2 * bsel:2 * bsel + 2], rtol=0, atol=3e-7), bsel     # torch row reductions: 1 ulp
+            assert torch.equal(one["profile_embeds"][0], full["profile_embeds"][bsel]), bsel
+            assert one["pick"] == full["pick"][4 * bsel:4 * bsel + 4], bsel
+            for j in range(4):
+                n = one["region_len"][j]
+                assert torch.equal(one["separated"][j, :n], full["separated"][4 * bsel + j, :n]), (bsel, j)
+            idx = [2 * bsel, 2 * bsel + 1] + [2 * B + 4 * bsel + j for j in range(4)]
+            for j, i in enumerate(idx):
+                assert one["records"][j]["tokens"] == full["records"][i]["tokens"], (bsel, j)
+                lp = full["records"][i]["sum_logprob"]
+                assert abs(one["records"][j]["sum_logprob"] - lp) < 2e-3 * max(1.0, abs(lp)), (bsel, j)
+    finally:
+        for m in ("separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
+            models[m].close()
+        for w in reversed(models["whisper_models"]):        # the taker of the shared encoder scratch before its donor
+            w.close()
+
+
+def test_rccl_executes_the_weight_broadcast_and_the_transcript_gather_on_one_rank(ccx_ctx):
+    """C1 / C2 of SURVEY.md 8e on the real backend: a one-rank `nccl` (= RCCL) process group runs `broadcast_weights` (packed uint8
+    blob through dist.broadcast; `force_collective` because a one-rank job would otherwise return its input) and
+    `gather_transcripts` (dist.all_gather of the fixed-size records).  tests/test_multirank_cpu.py covers world 2 on gloo; the
+    8-GPU run itself is the driver's."""
+    import socket
+    import torch.distributed as dist
+    from clearconverse_amd.batch import broadcast_weights, gather_transcripts
+    from clearconverse_amd.models import build_state_dicts
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        sds = build_state_dicts(None, whisper_dims=WhisperDims.mini(2, 128), sep_dims=SepDims(n_layers=1), seed=4)
+        sds["whisper"]["odd.int64"] = torch.arange(7, dtype=torch.int64)            # mixed dtypes and an odd byte count
+        sds["whisper"]["odd.bf16"] = torch.randn(5).to(torch.bfloat16)
+        got = broadcast_weights(sds, src=0, device=torch.device("cuda", 0), force_collective=True)
+        torch.cuda.synchronize()
+        n = 0
+        for model, sd in sds.items():
+            if not isinstance(sd, dict) or not any(torch.is_tensor(v) for v in sd.values()):
+                assert got[model] == sd, model
+                continue
+            assert set(got[model]) == set(sd), model
+            for k, v in sd.items():
+                if torch.is_tensor(v):
+                    assert got[model][k].dtype == v.dtype and got[model][k].shape == v.shape and torch.equal(got[model][k], v.cpu()), (model, k)
+                    n += 1
+                else:
+                    assert got[model][k] == v
+        assert n > 300
+        recs = [dict(tokens=[50363, 11, 12, 13]), dict(tokens=[]), dict(tokens=list(range(100, 108)))]
+        out = gather_transcripts(recs, 8, 50256, torch.device("cuda", 0))
+        assert out.shape == (3, 9) and out.dtype == torch.int32
+        assert out[0].tolist() == [4, 50363, 11, 12, 13, 50256, 50256, 50256, 50256] and out[1].tolist() == [0] + [50256] * 8
+        assert out[2].tolist() == [8] + list(range(100, 108))
+    finally:
+        dist.destroy_process_group()

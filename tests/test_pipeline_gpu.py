@@ -40,22 +40,54 @@ def test_vad_and_diarization_return_annotations(models, tmp_path):
     assert len(a) == len(b) and all(abs(x[0] - y[0]) < 0.02 and abs(x[1] - y[1]) < 0.02 for x, y in zip(a, b))   # 16-bit WAV quantisation
 
 
+@pytest.fixture(scope="module")
+def scripted_models(ccx_ctx):
+    """The same model set with SCRIPTED segmentation weights (tests/scripted_nets.py, fitted to synthetic_clip(1, 30 s)): VAD and
+    diarization then follow the clip's schedule (A 0-9 s, B 7-16 s, A 18-24 s, B 26-30 s), so `process_file` is guaranteed
+    speech regions, two diarization labels and an overlap -- a transcript must come out."""
+    from clearconverse_amd.models import build_state_dicts, load_models
+    from tests.scripted_nets import scripted_pyannet_state_dict
+    sds = build_state_dicts(None, whisper_dims=WhisperDims.mini(2, 128), sep_dims=SepDims(n_layers=2), seed=0)
+    sds["pyannet_diar"], _ = scripted_pyannet_state_dict(1, 7, True)
+    sds["pyannet_vad"], _ = scripted_pyannet_state_dict(1, 3, False, window_s=5.0, seed=4)
+    m = load_models(None, 0, whisper_batch=16, ctx=ccx_ctx, state_dicts=sds, sep_tokens=60_000, max_crops=128)
+    yield m
+    for k in ("whisper_model", "separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
+        m[k].close()
+
+
 @pytest.mark.parametrize("temperature", [0.0, 0.1])      # 0.1 = the reference's Config default (back/api.py:128)
-def test_processor_run_on_wav_file(models, tmp_path, temperature):
+def test_processor_run_on_wav_file(scripted_models, tmp_path, temperature):
+    """`EnhancedAudioProcessor.run` on a 30 s WAV (reference back/api.py:1204-1280): the transcript format of 1252-1265 is asserted
+    unconditionally -- the scripted segmentation weights guarantee speech, and min_speakers = max_speakers = 2 two diarization
+    labels (num_clusters is then forced to 2 whatever the seeded ResNet embeddings look like)."""
+    import re
     from clearconverse_amd.processor import Config, EnhancedAudioProcessor
-    clip = synthetic_clip(1, 30.0)[: 16000 * 10]
-    path = str(tmp_path / "ten.wav")
+    clip = synthetic_clip(1, 30.0)
+    path = str(tmp_path / "clip.wav")
     write_wav(path, clip)
-    p = EnhancedAudioProcessor(Config(temperature=temperature), load_models_immediately=False, model_loader=lambda cfg, dev: models)
+    p = EnhancedAudioProcessor(Config(temperature=temperature, min_speakers=2, max_speakers=2), load_models_immediately=False,
+                               model_loader=lambda cfg, dev: scripted_models)
     seen = []
     out = p.run(path, output_dir=str(tmp_path / "out"), progress_callback=lambda pct, msg: seen.append(pct))
     assert seen[:1] == [5] and 30 in seen
     assert isinstance(out, tuple) and len(out) == 3
-    if out[0] is not None:                         # random weights may legitimately detect no speaker
-        assert out[1].startswith("[SPEAKER_") or out[1].startswith("[UNKNOWN")
-        assert os.path.exists(out[2])
+    assert out[0] == path and out[1] is not None and os.path.exists(out[2])
+    pat = r"\[(SPEAKER_A|SPEAKER_B|UNKNOWN)\] (\d+\.\d\d)s - (\d+\.\d\d)s\n([^\n]*)\n\n"      # f"[{spk}] {start:.2f}s - {end:.2f}s\n{text}\n\n"
+    assert re.fullmatch(f"(?:{pat})+", out[1]), out[1]
+    blocks = re.findall(pat, out[1])
+    assert len(blocks) >= 2 and any(t.strip() for _, _, _, t in blocks)
+    speakers = set()
+    for spk, t0, t1, _ in blocks:
+        assert 0.0 <= float(t0) < float(t1) <= 31.0
+        speakers.add(spk)
+    assert {"SPEAKER_A", "SPEAKER_B"} <= speakers, speakers
+    with open(out[2], encoding="utf-8") as f:
+        assert f.read() == out[1]
+    res = p.process_file(path)
+    assert res["metadata"]["total_segments"] == len(res["segments"]) >= 2 and abs(res["metadata"]["duration"] - 30.0) < 1e-3
     audio, sr = p.load_audio(path)                  # A3 on the HIP spectral gate: peak-normalised
-    assert sr == 16000 and audio.shape == (1, 160000) and abs(float(audio.abs().max()) - 1.0) < 1e-4
+    assert sr == 16000 and audio.shape == (1, 480000) and abs(float(audio.abs().max()) - 1.0) < 1e-4
 
 
 def test_pinned_batch_driver_counts(models):

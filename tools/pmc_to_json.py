@@ -3,6 +3,9 @@ FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of wide coalesced 
 rocprofv3 section); WRITE_SIZE is exact; both are in KB."""
 import csv, json, sys, collections
 
+GRID = {}      # kernel -> set of Grid_Size values seen (the decode cross attention: sequences per launch = grid / 256 / heads)
+
+
 def load(path, counter):
     per = collections.defaultdict(lambda: [0, 0.0])
     seen = set()
@@ -13,18 +16,22 @@ def load(path, counter):
             name = r["Kernel_Name"]
             for pre in ("void ", "(anonymous namespace)::"):
                 name = name.replace(pre, "")
-            name = name.split("(")[0]
+            name = name.split("(")[0].replace(", ", ",")      # "dec_cross_stream_kernel<true,12,false>": the label bench.py uses
             key = (r["Dispatch_Id"], name)
             a = per[name]
             if key not in seen:
                 seen.add(key); a[0] += 1
+                g = r.get("Grid_Size") or r.get("Grid_Size_X")
+                if g:
+                    GRID.setdefault(name, set()).add(int(g))
             a[1] += float(r["Counter_Value"])
     return per
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
-note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --schedule sequential --steps 1 --warmup 0 --sample-len 4` "
-        "(pipeline workload, 32 clips, 192-sequence decode group in 3 lanes of 64); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+note = (sys.argv[4] if len(sys.argv) > 4 else
+        "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --schedule sequential --steps 1 --warmup 0 --sample-len 4` "
+        "(pipeline workload, 32 clips, 192-sequence decode group)") + ("; FETCH_SIZE doubled per MI355X_MICROARCH.md "
         "(gfx950 reports half of wide coalesced reads); KB units")
 for name in sorted(set(fetch) | set(write)):
     n = max(fetch.get(name, [0, 0])[0], write.get(name, [0, 0])[0])
@@ -48,15 +55,13 @@ for name, (n, fk, wk) in base.items():
     if name not in out:
         out[name] = {"launches": n, "FETCH_SIZE_kb_per_launch": fk / n, "WRITE_SIZE_kb_per_launch": wk / n,
                      "hbm_bytes_per_launch": (2.0 * fk + wk) / n * 1024.0, "note": note + "; all template instantiations together"}
-# Counter collection serialises dispatches, so the decode-lane stream probe finds no concurrent stream and the whole
-# 192-sequence group is decoded in ONE lane: the cross-attention launches of these passes cover 192 sequences.
+# Counter collection serialises dispatches, so the decode-lane stream probe finds no concurrent stream and a decode group runs in
+# ONE lane: the sequences a cross-attention launch covers are read off its grid (one 256-thread block per (sequence, head), 12 heads).
 for name in list(out):
-    if name.startswith("dec_attention_kernel"):
-        out[name]["sequences_per_launch"] = 192
-    if name.startswith("dec_cross_stream_kernel"):
-        # the lean-streaming cross attention: bench.py keeps the profile label of the kernel it replaced
-        out[name]["sequences_per_launch"] = 192
-        out["dec_attention_kernel<false>"] = dict(out[name], note=out[name]["note"] + "; measured on " + name)
+    if name.startswith("dec_cross_stream_kernel") and "false>" in name and GRID.get(name):
+        seqs = sorted(g // 256 // 12 for g in GRID[name])
+        out[name]["sequences_per_launch"] = seqs[-1] if len(seqs) == 1 else None
+        out[name]["sequences_per_launch_seen"] = seqs
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
 for k, v in top:
