@@ -148,6 +148,69 @@ def lane_cross_attention_in_situ(path, bytes_per_sequence):
     return out or None
 
 
+def single_file(args, rank, local_rank, world):
+    """The drop-in path as the reference calls it (back/api.py:1204-1280, one task = one file = one process): a step = one
+    `EnhancedAudioProcessor.run` on one 30 s / 16 kHz WAV -- file read, gate, VAD, diarization, profiles, per-segment embeddings,
+    overlap re-segmentation, separation and one B = 1 Whisper decode per segment (prompt-chained), segment WAVs and transcript
+    written.  Weights are seeded (no checkpoint offline), so VAD / diarization are computed and then replaced by the pinned
+    synthetic schedule, exactly as the pipeline workload does.  Latency mode: no roofline entry."""
+    import tempfile
+    from clearconverse_amd import _lib
+    from clearconverse_amd.audio import SCHEDULE_30S, synthetic_clip, write_wav
+    from clearconverse_amd.models import load_models
+    from clearconverse_amd.pipelines import Annotation
+    from clearconverse_amd.processor import Config, EnhancedAudioProcessor
+    ctx = _lib.Context(local_rank)
+    models = dict(load_models(None, local_rank, whisper_batch=8, ctx=ctx, seed=0, max_audio_seconds=30.0))
+
+    class Pinned:
+        """Runs the real pipeline (its cost stays in the step), returns the scheduled Annotation."""
+        def __init__(self, inner, tracks):
+            self.inner, self.tracks = inner, tracks
+
+        def __call__(self, path, **kw):
+            self.inner(path, **kw)
+            return Annotation(self.tracks)
+    speech = [(0.0, 16.0, "SPEECH"), (18.0, 24.0, "SPEECH"), (26.0, 30.0, "SPEECH")]
+    turns = [(s, e, "SPEAKER_00" if spk == "A" else "SPEAKER_01") for spk, s, e in SCHEDULE_30S]
+    models["vad_pipeline"] = Pinned(models["vad_pipeline"], speech)
+    models["diarization"] = Pinned(models["diarization"], turns)
+    work = tempfile.mkdtemp(prefix="ccx_single_file_")
+    n_files = max(1, min(8, args.steps))
+    wavs = []
+    for i in range(n_files):
+        wavs.append(os.path.join(work, f"clip{i}.wav"))
+        write_wav(wavs[-1], synthetic_clip(rank + world * i, 30.0))
+    proc = EnhancedAudioProcessor(Config(temperature=0.0), load_models_immediately=False, model_loader=lambda cfg, dev: models)
+    proc._initialize_models()
+    outs = []
+
+    def step(i):
+        out = proc.run(wavs[i % n_files], output_dir=os.path.join(work, f"out{i % n_files}"))
+        outs.append(out)
+        return out
+    for i in range(max(1, args.warmup)):
+        step(i)
+    torch.cuda.synchronize()
+    del outs[:]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        segs = [o[1].count("\n\n") if o[1] else 0 for o in outs]
+        print(json.dumps({
+            "metric": "xRT (audio-sec/wall-sec) end-to-end, 30 s 16 kHz clips", "value": round(30.0 * args.steps / dt, 2), "unit": "xRT",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic clips (seed 1234+i) as 16-bit WAV files, weights synthetic-seed0, greedy T=0",
+            "config": {"workload": "single_file: EnhancedAudioProcessor.run, one 30 s WAV per step (the reference's calling pattern, back/api.py:1204-1280)",
+                       "clips_per_gpu": 1, "clip_seconds": 30, "transcript_segments_per_file": segs[:8],
+                       "schedule": "VAD and diarization computed, then replaced by the pinned synthetic schedule (seeded weights); every "
+                                   "Whisper call is a B = 1 decode chained by its prompt; WAV read and segment / transcript files written inside the step"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     # every CCX_* switch of libccx found in the environment goes into the JSON line; the diagnostic ones that make results garbage
     # are refused (tools/README.md, "Measurement switches")
@@ -161,7 +224,9 @@ def main():
     # end to overlap with and reads ~5 % slower than the steady state the driver's --steps 20 --warmup 5 shows
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", choices=("pipeline", "whisper"), default="pipeline")
+    ap.add_argument("--workload", choices=("pipeline", "whisper", "single_file"), default="pipeline",
+                    help="pipeline = BASELINE configs[3] (default); whisper = configs[1]; single_file = the reference's own calling pattern: "
+                         "EnhancedAudioProcessor.run on one 30 s WAV at a time (B = 1 decodes chained by the prompt)")
     ap.add_argument("--batch", type=int, default=None, help="30 s clips per GPU per step (default 32 pipeline / 8 whisper)")
     ap.add_argument("--sample-len", type=int, default=224)
     ap.add_argument("--whisper-group", type=int, default=192, help="sequences decoded together in the pipeline workload")
@@ -205,6 +270,8 @@ def main():
                                            synthetic_resnet34_state_dict, synthetic_sepformer_state_dict, synthetic_whisper_state_dict,
                                            synthetic_xvector_state_dict)
 
+    if args.workload == "single_file":
+        return single_file(args, rank, local_rank, world)
     pipeline = args.workload == "pipeline"
     B = args.batch or (32 if pipeline else 8)
     rules = DecodeRules()
@@ -482,6 +549,16 @@ def main():
             cpu = dict(value=round(xrt, 3), unit="xRT (audio-sec/wall-sec)", cores=threads, kind="port",
                        method="extrapolated: bounded op samples x one clip's op counts" if pipeline else "measured end to end on one clip",
                        sample=sample)
+            if pipeline:
+                # one full clip WAS timed end to end through the same oracle pipeline on a GPU box's host cores (tools/cpu_full_clip.py,
+                # once per round, committed): how far the extrapolation above is from it
+                full = sorted((ROOT / "profiles").glob("r*_cpu_full_clip.json"))
+                if full:
+                    fc = json.loads(full[-1].read_text())
+                    cpu["measured_full_clip"] = dict(file=f"profiles/{full[-1].name}", xrt=fc["xrt"], total_s=fc["total_s"], threads=fc["threads"],
+                                                     extrapolated_over_measured=round(xrt / fc["xrt"], 3))
+                    cpu["sample"] += (f"; one full clip measured end to end on {fc['threads']} threads of a GPU box: {fc['total_s']} s = {fc['xrt']} xRT "
+                                      f"({full[-1].name}), this run's extrapolation / that measurement = {xrt / fc['xrt']:.2f}")
 
         enc_f, cross_f = enc_flops_per_window(dims)
         cfg = {"workload": "full_pipeline_vad_diarize_separate_transcribe (BASELINE configs[3])" if pipeline

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import within
+
 pytestmark = pytest.mark.gpu
 
 
@@ -129,7 +131,7 @@ def test_enc_attention(ccx_ctx, B, H, S):
     got = o.float().cpu()
     assert torch.isfinite(got).all()
     # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative
-    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    within("enc_attention_kernel: output rel-L2", _rel(got, ref), 1e-2)
     assert float((got - ref).abs().max()) < 0.06
 
 

@@ -20,8 +20,14 @@ import torch
 
 from clearconverse_amd.audio import synthetic_clip
 from clearconverse_amd.weights import SepDims, WhisperDims
+from tests.conftest import within
 
 pytestmark = pytest.mark.gpu
+
+
+# bounds of test_run_pinned_matches_oracle_composed_pipeline, per tracked quantity (also asserted inline below)
+BOUNDS = {"vad_boundary_s": 270 / 16000 + 1e-9, "diarization_disagreement": 3e-2, "den": 1e-5, "profile_embed": 1e-2, "profile": 1e-2,
+          "sim": 2e-4, "window_sim": 2e-4, "separated": 2e-2, "source_sim": 2e-4}
 
 
 def _rel(a, b):
@@ -58,6 +64,7 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
 
     def track(name, v):
         worst[name] = max(worst.get(name, 0.0), float(v))
+        within("run_pinned vs oracle pipeline (mini Whisper, 2-layer SepFormer): " + name, v, BOUNDS[name])
 
     for b, clip in enumerate(clips):
         # A14 / A13 (reference back/api.py:1311-1312, 1052-1064): the VAD and diarization the pinned pipeline computes on the raw

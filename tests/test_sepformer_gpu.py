@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import within
+
 from clearconverse_amd.weights import SepDims, synthetic_sepformer_state_dict
 from oracle import sepformer_ref as S
 
@@ -47,7 +49,7 @@ def test_separate_matches_oracle_ragged(small):
     for i, n in enumerate(lengths):
         ref = orc.separate(mix[i:i + 1, :n])[0]
         assert torch.isfinite(got[i]).all()
-        assert _rel(got[i, :n], ref) < 3e-2, (i, _rel(got[i, :n], ref))
+        within("sepformer 2-layer: separated waveform rel-L2 (ragged batch)", _rel(got[i, :n], ref), 3e-2, i)
         assert float(got[i, n:].abs().max()) == 0.0 if n < mix.shape[1] else True
 
 
@@ -69,7 +71,7 @@ def test_full_depth_model(ccx_ctx):
         got = m.separate_batch(mix).cpu()
         ref = S.SepformerRef(S.SepDims(**dims.__dict__), sd).separate(mix)
         assert got.shape == (1, 12000, 2)
-        assert _rel(got, ref) < 5e-2, _rel(got, ref)
+        within("sepformer FULL depth (8 layers x 3 blocks): separated waveform rel-L2", _rel(got, ref), 5e-2)
     finally:
         m.close()
 
