@@ -142,9 +142,12 @@ def lane_cross_attention_in_situ(path, bytes_per_sequence):
         d = (t[1:] - t[:-1])[tag[1:] == 2] / 1e3                 # us, intervals that END at a tag-2 stamp = one cross attention
         d = d[len(d) // 4:]                                        # skip the eager first step and the capture pass
         rows = min(per, B - lane * per)
+        ends = t[tag == 3]                                         # one stamp at the end of every decode step of the lane
+        st = np.diff(ends)[len(ends) // 4:] / 1e3
         if len(d) and rows > 0:
             out.append(dict(lane=lane, sequences=rows, launches=int(len(d)), median_us=float(np.median(d)), p90_us=float(np.percentile(d, 90)),
-                            gbs=rows * bytes_per_sequence / (float(np.median(d)) * 1e-6) / 1e9))
+                            gbs=rows * bytes_per_sequence / (float(np.median(d)) * 1e-6) / 1e9,
+                            step_median_us=float(np.median(st)) if len(st) else None))
     return out or None
 
 
@@ -507,6 +510,16 @@ def main():
                 gbs = float(np.mean([l["gbs"] for l in in_situ]))
                 roof["achieved_in_situ"] = round(gbs, 1)
                 roof["frac_in_situ"] = round(gbs / PEAK_HBM_GBS, 4)
+                steps = [l["step_median_us"] for l in in_situ if l.get("step_median_us")]
+                if steps:
+                    # the WHOLE decode step of the group: every lane's cross-KV + the decoder weights each lane streams once per step
+                    # (self-KV is < 1 % at the trace's <= 24 positions), all lanes concurrent, over the median lane step time
+                    by_step = float(sum(decode_bytes_per_step(dims, l["sequences"]) for l in in_situ))
+                    roof["decode_step_in_situ"] = dict(bytes=by_step, median_us=round(float(np.mean(steps)), 1),
+                                                       achieved=round(by_step / (float(np.mean(steps)) * 1e-6) / 1e9, 1),
+                                                       frac=round(by_step / (float(np.mean(steps)) * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), unit="GB/s",
+                                                       what="all kernels of one decode step of the whole group (cross attention, self attention, "
+                                                            "linears, logits, select), lanes concurrent, graph replay")
                 roof["in_situ"] = dict(lanes=[{k: (round(v, 1) if isinstance(v, float) else v) for k, v in l.items()} for l in in_situ],
                                        measured="in-graph s_memrealtime stamps around every layer's cross attention (ccx_whisper_trace_lanes), "
                                                 f"graph replay of a {Bd}-sequence group, all lanes concurrent; includes the ~2 us stamp nodes")

@@ -140,8 +140,11 @@ class Context:
         if rc != 0:
             raise CcxError(f"{what or 'ccx call'} failed ({rc}): {self.lib.ccx_last_error(self.handle).decode()}")
 
+    prof_on = False
+
     def prof_enable(self, on: bool = True):
         self.check(self.lib.ccx_prof_enable(self.handle, 1 if on else 0), "ccx_prof_enable")
+        self.prof_on = bool(on)
 
     def prof_records(self):
         """[(kernel name, algorithmic flops, algorithmic bytes, ms)] for every recorded launch."""

@@ -238,6 +238,9 @@ class BatchPipeline:
         whs = self.m.get("whisper_models") or [self.m["whisper_model"]]
         if len(whs) < 2:
             raise _lib.CcxError("run_pinned_pipelined needs two Whisper instances: load_models(..., whisper_instances=2)")
+        if self.ctx.prof_on:
+            raise _lib.CcxError("run_pinned_pipelined: switch the per-launch profile off (ctx.prof_enable(False)) -- it is recorded per "
+                                "context, and this schedule drives the context from two host threads")
         dev = audios[0].device
         if not hasattr(self, "_front_stream"):
             self._front_stream = torch.cuda.Stream(device=dev)

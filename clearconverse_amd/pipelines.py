@@ -60,8 +60,13 @@ class Annotation:
         return len(self._tracks)
 
 
-def load_mono_16k(path_or_wave):
-    """The pipelines read the file themselves (raw, NOT denoised -- SURVEY.md section 3b)."""
+_RESAMPLERS: Dict[Tuple[int, int], SincResampler] = {}      # (source rate, device index) -> resampler (filter table uploaded once)
+
+
+def load_mono_16k(path_or_wave, device: Optional[torch.device] = None, ctx=None):
+    """The pipelines read the file themselves (raw, NOT denoised -- SURVEY.md section 3b).  Returns a 1-D float32 signal at
+    16 kHz: a tensor on `device` when it is already resident there or had to be resampled (K1 runs on the device), a host numpy
+    array otherwise (the callers move their windows to the device themselves)."""
     if isinstance(path_or_wave, dict):
         w = path_or_wave["waveform"]
         sr = int(path_or_wave.get("sample_rate", SR))
@@ -74,7 +79,11 @@ def load_mono_16k(path_or_wave):
     if x.ndim > 1:
         x = x.mean(axis=0)
     if sr != SR:
-        return SincResampler(sr, SR)(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))     # K1 on the device, stays resident
+        idx = device.index if isinstance(device, torch.device) and device.index is not None else 0
+        rs = _RESAMPLERS.get((sr, idx))
+        if rs is None:
+            rs = _RESAMPLERS[(sr, idx)] = SincResampler(sr, SR, device=idx, ctx=ctx)
+        return rs(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))     # K1 on the pipeline's device, stays resident
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
@@ -230,7 +239,7 @@ class VoiceActivityDetection:
     def begin(self, items: Sequence):
         """Cut the windows of all items and QUEUE the network; returns a handle for `finish`.  Nothing waits for the GPU
         here, so a caller can queue more work (e.g. the diarization network) before collecting."""
-        xs = [load_mono_16k(it) for it in items]
+        xs = [load_mono_16k(it, self.net.device, getattr(self.net, "ctx", None)) for it in items]
         plans, crops = [], []
         for x in xs:
             if len(x) < 991 * 4:
@@ -358,7 +367,7 @@ class SpeakerDiarization:
     # embed  -- fetch the frame scores, pick the local speakers' pooling masks on the host, QUEUE the embedding network;
     # finish -- fetch the embeddings, cluster and rebuild the timelines on the host.
     def begin(self, items: Sequence):
-        xs = [load_mono_16k(it) for it in items]
+        xs = [load_mono_16k(it, self.net.device, getattr(self.net, "ctx", None)) for it in items]
         plans, crops = [], []
         for x in xs:
             if len(x) < 991 * 4:

@@ -352,7 +352,10 @@ PYANNOTE_PIPELINES = {
     "vad": ("pyannote/voice-activity-detection", "vad"),
     "diarization": ("pyannote/speaker-diarization-3.1", "speaker-diarization"),
 }
-# defaults = the published config.yaml values as recalled; a config.yaml found on disk overrides them
+# defaults = published values as recalled [UPSTREAM-RECALL]; a config.yaml found on disk overrides them.  The VAD numbers are the
+# ones the `pyannote/segmentation` model card gives for voice activity detection on AMI (onset 0.767 / offset 0.377 / min_duration_on
+# 0.136 / min_duration_off 0.067); whether `pyannote/voice-activity-detection`'s own config.yaml carries exactly these is NOT
+# verifiable offline (parity unpinned) -- they only apply when that file is absent from MODEL_CACHE_DIR.
 VAD_DEFAULTS = dict(onset=0.767, offset=0.377, min_duration_on=0.136, min_duration_off=0.067)
 DIAR_DEFAULTS = dict(threshold=0.7045654963945799, min_cluster_size=12, min_duration_off=0.0, method="centroid")
 
@@ -414,7 +417,10 @@ def _conform(kind: str, sd: Dict[str, torch.Tensor], schema: Dict[str, torch.Ten
         if k not in sd:
             raise ValueError(f"{path}: {kind} checkpoint lacks '{k}' (not the architecture built here)")
         if tuple(sd[k].shape) != tuple(ref.shape):
-            if sd[k].numel() == ref.numel():
+            # only size-1 dimensions may differ (a Conv1d weight saved as [out, in, 1] for a Linear, a squeezed scalar ...): the
+            # element ORDER is then unchanged.  Any other same-numel mismatch (a transposed or permuted weight) is an error
+            squeeze = lambda shp: tuple(int(d) for d in shp if int(d) != 1)
+            if squeeze(sd[k].shape) == squeeze(ref.shape):
                 out[k] = sd[k].reshape(ref.shape)
                 continue
             raise ValueError(f"{path}: '{k}' has shape {tuple(sd[k].shape)}, expected {tuple(ref.shape)}")

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import within
+
 from clearconverse_amd import _lib
 from clearconverse_amd.audio import synthetic_clip
 from clearconverse_amd.weights import (SepDims, WhisperDims, synthetic_pyannet_state_dict, synthetic_sepformer_state_dict,
@@ -61,7 +63,7 @@ def test_separator_short_and_ragged(ccx_ctx):
     orc = S.SepformerRef(S.SepDims(**dims.__dict__), sd)
     ref = orc.separate(mix[1:2, :40].cpu())
     got = out[1:2, :40].cpu()
-    assert float((got - ref).norm() / (ref.norm() + 1e-9)) < 5e-2
+    within("sepformer 2-layer: 40-sample utterance rel-L2", float((got - ref).norm() / (ref.norm() + 1e-9)), 5e-2)
     with pytest.raises(_lib.CcxError):
         sep.separate_batch(mix, [4000, 0, 10])                             # an empty utterance is an error, not a crash
 

@@ -103,7 +103,7 @@ def test_layernorm(ccx_ctx, M, D):
                                    ob.data_ptr(), of.data_ptr(), M, D, 1e-5, _stream())
     ccx_ctx.check(rc, "layernorm")
     torch.cuda.synchronize()
-    assert float((of.cpu() - ref).abs().max()) < 2e-5
+    within("layernorm_kernel: fp32 output max abs error", float((of.cpu() - ref).abs().max()), 2e-5)
     assert float((ob.float().cpu() - ref).abs().max()) < 0.03
 
 
@@ -131,7 +131,7 @@ def test_enc_attention(ccx_ctx, B, H, S):
     got = o.float().cpu()
     assert torch.isfinite(got).all()
     # P is rounded to bf16 before P.V and the output is bf16: ~2^-8 relative
-    within("enc_attention_kernel: output rel-L2", _rel(got, ref), 1e-2)
+    within("enc_attention_kernel: output rel-L2", _rel(got, ref), 4e-3)
     assert float((got - ref).abs().max()) < 0.06
 
 

@@ -8,10 +8,11 @@
     on its batch mates: clips run alone give identical tokens, bit-identical embeddings and separated waveforms, similarities
     equal to 1 ulp and log-probabilities equal to 4e-4 relative (reasons next to the assertions).
 
-Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages; about 4x the worst deviation measured on MI355X, which is given
-in brackets): gated + normalised clip rel-L2 1e-5 [2e-7]; profile embeddings rel-L2 1e-2 [2.5e-3]; cosine similarities abs 2e-4
-[3e-5] (seeded random x-vector weights give similarities of 0.996-0.999, so the tolerance is set against their spread, not
-against 1); separated waveforms rel-L2 2e-2 [4e-3]; the picked source must agree wherever the oracle's two similarities differ
+Tolerances (fp32 oracle vs bf16-MFMA kernels, chained stages; BOUNDS below, <= 2.5x the worst deviation measured on MI355X, which is
+given in brackets): gated + normalised clip rel-L2 5e-7 [2e-7]; profile embeddings rel-L2 6e-3 [2.5e-3]; cosine similarities abs 2e-5 /
+window 5e-5 / source 3e-5 [8e-6 / 2.4e-5 / 1.2e-5] (seeded random x-vector weights give similarities of 0.996-0.999, so the tolerance
+is set against their spread, not against 1); separated waveforms rel-L2 8e-3 [4e-3]; VAD boundaries within one frame [0];
+diarization timelines differ on <= 0.05 % of the (time, speaker) cells [0.019 %]; the picked source must agree wherever the oracle's two similarities differ
 by more than 5e-4; Whisper tokens are eps-argmax (eps 0.1: gate + separator + encoder + decoder errors in series) of the oracle's
 filtered logits under teacher forcing and equal where its margin exceeds 2 eps (27 of the 72 steps)."""
 import numpy as np
@@ -26,8 +27,9 @@ pytestmark = pytest.mark.gpu
 
 
 # bounds of test_run_pinned_matches_oracle_composed_pipeline, per tracked quantity (also asserted inline below)
-BOUNDS = {"vad_boundary_s": 270 / 16000 + 1e-9, "diarization_disagreement": 3e-2, "den": 1e-5, "profile_embed": 1e-2, "profile": 1e-2,
-          "sim": 2e-4, "window_sim": 2e-4, "separated": 2e-2, "source_sim": 2e-4}
+# (<= 2.5x the worst deviation measured on MI355X, profiles/r03_measured_deviations.json; round 2's bounds were 4-25x)
+BOUNDS = {"vad_boundary_s": 270 / 16000 + 1e-9, "diarization_disagreement": 5e-4, "den": 5e-7, "profile_embed": 6e-3, "profile": 5e-3,
+          "sim": 2e-5, "window_sim": 5e-5, "separated": 8e-3, "source_sim": 3e-5}
 
 
 def _rel(a, b):
@@ -77,34 +79,27 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx):
         assert dev <= 270 / 16000 + 1e-9, (b, dev)
         agree = O.timeline_agreement(r["diarization"][b], po["diarization"], 40.0)
         track("vad_boundary_s", dev); track("diarization_disagreement", 1.0 - agree)
-        assert agree >= 0.97 and len(r["diarization"][b]) >= 2, (b, agree)
+        assert len(r["diarization"][b]) >= 2, b
         o = O.run_clip(clip, sds, sdims)
         track("den", _rel(r["den"][b], o["den"]))
-        assert _rel(r["den"][b], o["den"]) < 1e-5
         for j in range(4):
             track("profile_embed", _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]))
-            assert _rel(r["profile_embeds"][b, j], o["profile_embeds"][j]) < 1e-2
             assert abs(float(r["profile_var"][b, j]) - o["profile_var"][j]) < 1e-3 * o["profile_var"][j]
         for spk in ("A", "B"):
             track("profile", _rel(r["profiles"][spk][b], o["profiles"][spk]))
-            assert _rel(r["profiles"][spk][b], o["profiles"][spk]) < 1e-2
         for j in range(2):
             d = abs(r["sims"][2 * b + j] - o["sims"][j]); track("sim", d)
-            assert d < 2e-4, (b, j, r["sims"][2 * b + j], o["sims"][j])
         rows = [i for i, ow in enumerate(r["window_owner"]) if ow // 2 == b]
         assert len(rows) == len(o["window_sims"]) == 42
         ws = r["window_sims_full"][rows]
         d = float((ws - torch.tensor(o["window_sims"])).abs().max()); track("window_sim", d)
-        assert d < 2e-4
         for k in range(4):
             i = 4 * b + k
             assert r["regions"][i][1:] == o["regions"][k] and r["region_len"][i] == o["regions"][k][2] - o["regions"][k][1]
             n = r["region_len"][i]
             e = _rel(r["separated"][i, :n], o["separated"][k]); track("separated", e)
-            assert e < 2e-2, (i, e)
             ss = o["source_sims"][k]
             d = float((r["source_sims"][i] - torch.tensor(ss)).abs().max()); track("source_sim", d)
-            assert d < 2e-4
             if abs(ss[1] - ss[0]) > 5e-4:
                 n_pick += 1
                 assert r["pick"][i] == int(ss[1] > ss[0]), (i, ss, r["pick"][i])

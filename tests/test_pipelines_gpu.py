@@ -9,12 +9,14 @@ speakers, an overlap, realistic flicker at syllable troughs).  Parity unpinned: 
 Three levels:
  (1) the post-net in isolation on REAL network outputs: the oracle post-net fed with the GPU's own frame scores and embeddings
      must return exactly the product's Annotation (same labels, same boundaries to the last bit);
- (2) network decisions: the hard multi-label activity decoded from GPU and oracle scores agrees on >= 99.5 % of the frames,
-     embeddings of the oracle's masks agree to rel-L2 3e-2;
+ (2) network decisions: the hard multi-label activity decoded from GPU and oracle scores agrees on >= 99.9 % of the frames (measured 99.97 %),
+     embeddings of the oracle's masks agree to rel-L2 8e-3 (measured 3.1e-3);
  (3) end to end (HIP nets + product post-net vs oracle nets + oracle post-net): VAD region count equal and boundaries within
-     one frame (270 samples); diarization timelines agree on >= 98 % of the (time, speaker) cells up to a label permutation --
+     one frame (270 samples); diarization timelines agree on >= 99.85 % of the (time, speaker) cells (measured 99.94 %) up to a label permutation --
      a frame whose top-2 margin is below the bf16 error may flip a one-frame segment, and the clustering of seeded ResNet
-     embeddings (cosine ~0.99 between any two) is not a stable function of its input bits."""
+     embeddings (cosine ~0.99 between any two) is not a stable function of its input bits.
+Bounds are <= 2.5x the worst deviation measured on MI355X (profiles/r03_measured_deviations.json); tests.conftest.within records
+every measured value again on each run."""
 import numpy as np
 import pytest
 import torch
@@ -88,8 +90,8 @@ def test_network_decisions_match_the_oracle_networks(nets):
     # error is ~10x that of the seeded-weight test (test_speaker_gpu.py: 5e-2); what matters here are the DECISIONS: identical wherever
     # the oracle's top-2 margin exceeds 1.0, and >= 99.5 % of all frames
     print(f"scripted segmentation: hard multi-label agreement {agree:.4f}, max |log-prob error| {worst:.3e}")
-    within("pyannet scripted weights: 1 - hard multi-label agreement with the oracle", 1.0 - agree, 5e-3)
-    within("pyannet scripted weights: log-prob max abs error (logit span +-12)", worst, 0.5)
+    within("pyannet scripted weights: 1 - hard multi-label agreement with the oracle", 1.0 - agree, 1e-3)
+    within("pyannet scripted weights: log-prob max abs error (logit span +-12)", worst, 0.45)
     for g, o in zip(gpu, orc):
         top2 = np.sort(o, axis=-1)[:, -2:]
         decided = (top2[:, 1] - top2[:, 0]) > 1.0
@@ -97,7 +99,7 @@ def test_network_decisions_match_the_oracle_networks(nets):
     _, ch5 = O.cut_chunks(clip, 80000, 8000)
     gv = nets["seg_v"].segment_numpy([torch.from_numpy(c) for c in ch5])
     ov = oracle_seg_fn(nets["sd_vad"], False)(ch5)
-    within("pyannet scripted weights (VAD, sigmoid): frame score max abs error", max(float(np.abs(g - o).max()) for g, o in zip(gv, ov)), 5e-2)
+    within("pyannet scripted weights (VAD, sigmoid): frame score max abs error", max(float(np.abs(g - o).max()) for g, o in zip(gv, ov)), 3e-2)
     # embeddings of the ORACLE's masks (the pooling masks the pipeline would hand over) for four windows
     rel = 0.0
     for c in (0, 7, 12, 20):
@@ -107,7 +109,7 @@ def test_network_decisions_match_the_oracle_networks(nets):
         ref = W.resnet_embed(nets["rsd"], chunks[c][None], masks, np.zeros(len(masks), dtype=np.int64))
         rel = max(rel, float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
     print(f"ResNet-34 embeddings of the oracle's pooling masks: worst rel-L2 {rel:.3e}")
-    within("resnet34: embedding rel-L2 (pipeline pooling masks, 10 s chunks)", rel, 3e-2)
+    within("resnet34: embedding rel-L2 (pipeline pooling masks, 10 s chunks)", rel, 8e-3)
 
 
 def test_pipelines_end_to_end_against_the_oracle_pipelines(nets):
@@ -122,10 +124,11 @@ def test_pipelines_end_to_end_against_the_oracle_pipelines(nets):
         got_v = [(s, e) for s, e, _ in _tracks(vad(item))]
         assert len(got_v) == len(want["vad"]) >= 2, (name, got_v, want["vad"])
         dev = max(max(abs(a[0] - b[0]), abs(a[1] - b[1])) for a, b in zip(got_v, want["vad"]))
-        assert dev <= FRAME + 1e-9, (name, dev)
+        within("pipelines end to end: VAD boundary deviation (s)", dev, FRAME + 1e-9, name)
         got_d = _tracks(dia(item, min_speakers=1, max_speakers=2))
         agree = PO.timeline_agreement(got_d, want["diarization"], len(clip) / 16000 + 10.0)
         n_lab = (len({l for *_, l in got_d}), len({l for *_, l in want["diarization"]}))
         print(f"{name}: VAD {len(got_v)} regions, worst boundary deviation {dev * 1e3:.1f} ms; diarization {len(got_d)} vs "
               f"{len(want['diarization'])} turns, labels {n_lab}, agreement {agree:.4f}")
-        assert agree >= 0.98 and n_lab[0] == n_lab[1], (name, agree, n_lab)
+        within("pipelines end to end: diarization timeline disagreement with the oracle pipeline", 1.0 - agree, 1.5e-3, name)
+        assert n_lab[0] == n_lab[1], (name, n_lab)

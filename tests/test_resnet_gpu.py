@@ -1,5 +1,5 @@
 """GPU parity of the WeSpeaker ResNet-34 embedder (K21, csrc/resnet.hip) against oracle/wespeaker_ref.py,
-through the C ABI (ccx_resnet_*).  Tolerance: rel-L2 <= 3e-2 on the embedding (bf16 activations through
+through the C ABI (ccx_resnet_*).  Tolerance: rel-L2 <= 8e-3 (measured 3.6e-3) on the embedding (bf16 activations through
 33 convolutions against the fp32 restatement; SURVEY.md 8c states 1e-2 per bf16 tensor)."""
 import numpy as np
 import pytest
@@ -12,7 +12,7 @@ from clearconverse_amd.weights import synthetic_resnet34_state_dict
 from oracle import wespeaker_ref as R
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-2
+TOL = 8e-3      # rel-L2 of the 256-d embedding; worst measured on MI355X 3.6e-3 (profiles/r03_measured_deviations.json)
 
 
 def _clip(seed, n, off=0):

@@ -1,5 +1,5 @@
 """-m gpu: RE-SepFormer through the C ABI vs oracle/sepformer_ref.py (CPU fp32).
-Tolerance: separated waveforms rel-L2 <= 3e-2 (bf16 GEMM inputs / bf16 attention probabilities through
+Tolerance: separated waveforms rel-L2 <= 8e-3 (9e-3 at full depth; measured 3.9e-3 / 4.4e-3 on MI355X, profiles/r03_measured_deviations.json; was 3e-2 / 5e-2) (bf16 GEMM inputs / bf16 attention probabilities through
 2 x 8 + 8 transformer layers; fp32 residual stream and norms) -- SURVEY.md section 8c states 1e-2 for
 single bf16 stages."""
 import numpy as np
@@ -49,7 +49,7 @@ def test_separate_matches_oracle_ragged(small):
     for i, n in enumerate(lengths):
         ref = orc.separate(mix[i:i + 1, :n])[0]
         assert torch.isfinite(got[i]).all()
-        within("sepformer 2-layer: separated waveform rel-L2 (ragged batch)", _rel(got[i, :n], ref), 3e-2, i)
+        within("sepformer 2-layer: separated waveform rel-L2 (ragged batch)", _rel(got[i, :n], ref), 8e-3, i)
         assert float(got[i, n:].abs().max()) == 0.0 if n < mix.shape[1] else True
 
 
@@ -71,7 +71,7 @@ def test_full_depth_model(ccx_ctx):
         got = m.separate_batch(mix).cpu()
         ref = S.SepformerRef(S.SepDims(**dims.__dict__), sd).separate(mix)
         assert got.shape == (1, 12000, 2)
-        within("sepformer FULL depth (8 layers x 3 blocks): separated waveform rel-L2", _rel(got, ref), 5e-2)
+        within("sepformer FULL depth (8 layers x 3 blocks): separated waveform rel-L2", _rel(got, ref), 9e-3)
     finally:
         m.close()
 

@@ -47,7 +47,7 @@ def test_xvector_matches_oracle_ragged(ccx_ctx):
         for i, c in enumerate(crops):
             ref = P.xvector_forward(sd, c[None])
             assert torch.isfinite(got[i]).all()
-            within("x-vector: embedding rel-L2", _rel(got[i], ref), 2e-2, i)
+            within("x-vector: embedding rel-L2", _rel(got[i], ref), 7e-3, i)
             cos = torch.nn.functional.cosine_similarity(got[i], ref, dim=0).item()
             assert cos > 0.9995
         # reference call shape (back/api.py:869-872)
@@ -98,7 +98,7 @@ def test_pyannet_matches_oracle(ccx_ctx, powerset, n_classes):
             ref = P.pyannet_forward(osd, c[None, None])[0]
             got = got.cpu()
             assert got.shape == ref.shape, (got.shape, ref.shape)
-            within(f"pyannet ({n_classes} classes): frame score max abs error (seeded weights)", float((got - ref).abs().max()), 5e-2)
+            within(f"pyannet ({n_classes} classes): frame score max abs error (seeded weights)", float((got - ref).abs().max()), 2.5e-3)
             top2 = torch.topk(ref, 2, dim=-1).values
             decided = (top2[:, 0] - top2[:, 1]) > 0.1
             assert torch.equal(got.argmax(-1)[decided], ref.argmax(-1)[decided])

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import within
+
 from clearconverse_amd.audio import synthetic_clip
 from oracle.spectral_gate_ref import reduce_noise
 
@@ -26,7 +28,7 @@ def test_matches_oracle(ccx_ctx, seconds, prop):
         ref = reduce_noise(x, 16000, prop)
         assert got.shape == ref.shape and got.dtype == np.float32
         assert np.isfinite(got).all()
-        assert _rel(got, ref) < 2e-3, _rel(got, ref)
+        within("spectral gate: denoised clip rel-L2", _rel(got, ref), 2e-3)
     finally:
         g.close()
 
@@ -59,8 +61,8 @@ def test_long_signal_chunked_path_matches_oracle(ccx_ctx, seconds):
         got = g(x, 16000, 0.5)
         ref = reduce_noise(x, 16000, 0.5)
         assert got.shape == ref.shape
-        assert _rel(got, ref) < 2e-3, _rel(got, ref)
+        within("spectral gate (chunked, > 37.5 s): denoised signal rel-L2", _rel(got, ref), 2e-3)
         for seam in range(600000, n, 600000):              # no discontinuity at a chunk seam
-            assert _rel(got[seam - 2000:seam + 2000], ref[seam - 2000:seam + 2000]) < 5e-3
+            within("spectral gate (chunked): rel-L2 of 4000 samples around a chunk seam", _rel(got[seam - 2000:seam + 2000], ref[seam - 2000:seam + 2000]), 5e-3)
     finally:
         g.close()

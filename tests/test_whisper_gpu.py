@@ -64,7 +64,7 @@ def test_logmel_matches_oracle(mini):
         full = R.log_mel_spectrogram(torch.from_numpy(c))
         content = len(c) // 160
         ref = R.pad_or_trim(full[:, : min(3000, content)], 3000)
-        within("whisper: log-mel max abs error", float((mel[b] - ref).abs().max()), 2e-3, b)
+        within("whisper: log-mel max abs error", float((mel[b] - ref).abs().max()), 1e-4, b)
 
 
 def test_logmel_seek_window(mini):
@@ -85,7 +85,7 @@ def test_encoder_mini(mini):
     xa = m.encode(2, return_xa=True).cpu()
     ref = _oracle(dims, sd).encode(mel.cpu())
     assert torch.isfinite(xa).all()
-    within("whisper mini: encoder output rel-L2", _rel(xa, ref), 2e-2)
+    within("whisper mini: encoder output rel-L2", _rel(xa, ref), 8e-3)
 
 
 def test_set_mel_path_equals_logmel_path(mini):
@@ -108,12 +108,12 @@ def test_decoder_logits_mini(mini):
     toks[:, 0] = 50257
     got = m.decoder_logits(toks.numpy()).cpu()
     ref = _oracle(dims, sd).decoder_logits(toks, xa.cpu())   # oracle decoder on the GPU's own xa: isolates the decoder
-    within("whisper mini: decoder logits rel-L2 (teacher forced, 2 x 9 positions)", _rel(got, ref), 3e-2)
+    within("whisper mini: decoder logits rel-L2 (teacher forced, 2 x 9 positions)", _rel(got, ref), 9e-3)
     # n_vocab % 16 == 8: the logits GEMM stores whole 16-column groups, so an in-place [B, T, V] store would overwrite the first
     # 8 logits of the next row (b + 1, t = 0) at t = T - 1 -- every (b, t) row is checked on its own
     for b in range(2):
         for t in range(9):
-            within("whisper mini: decoder logits rel-L2 (per position)", _rel(got[b, t], ref[b, t]), 3e-2, (b, t))
+            within("whisper mini: decoder logits rel-L2 (per position)", _rel(got[b, t], ref[b, t]), 1e-2, (b, t))
     assert float((got[1, 0, :8] - ref[1, 0, :8]).abs().max()) < 0.05 * float(ref[1, 0].abs().max())
     # T == 1 (a single teacher-forced position)
     one = m.decoder_logits(toks[:, :1].numpy()).cpu()
@@ -160,8 +160,8 @@ def _check_greedy(dims, sd, m, xa, prompts, sample_len, tol):
                 assert t == int(lg.argmax())
                 n_exact_required += 1
             seq.append(t); sampled.append(t)
-        assert abs(o.sum_logprob - r["sum_logprob"]) < 0.05 * max(1.0, abs(o.sum_logprob)) + tol * len(forced)
-        assert abs(o.no_speech_prob - r["no_speech_prob"]) < 1e-3 + 0.05 * o.no_speech_prob
+        within("whisper greedy: |sum_logprob - oracle (teacher forced)| / max(1, |oracle|)", abs(o.sum_logprob - r["sum_logprob"]) / max(1.0, abs(o.sum_logprob)), 0.05 + tol * len(forced) / max(1.0, abs(o.sum_logprob)))
+        within("whisper greedy: |no_speech_prob - oracle|", abs(o.no_speech_prob - r["no_speech_prob"]), 1e-3 + 0.05 * o.no_speech_prob)
     return res, n_exact_required
 
 
@@ -263,7 +263,7 @@ def test_small_en_full_size(ccx_ctx):
         mel = m.log_mel(dev, n, return_mel=True)
         xa = m.encode(2, return_xa=True).cpu()
         ref = _oracle(dims, sd).encode(mel.cpu())
-        within("whisper small.en FULL size: encoder output rel-L2", _rel(xa, ref), 2e-2)
+        within("whisper small.en FULL size: encoder output rel-L2", _rel(xa, ref), 9.5e-3)
         _check_greedy(dims, sd, m, xa, [[rules.sot], [rules.sot_prev, 1212, 318, rules.sot]], sample_len=6, tol=0.08)
     finally:
         m.close()
