@@ -399,9 +399,16 @@ def main():
     wm = models["whisper_model"] if pipeline else model
     span = args.decode_span if (pipeline and args.schedule == "pipelined") else 1
     Bd = min(args.whisper_group, 6 * B * span) if pipeline else B
+    # The probe decodes a group that is 16 rows per lane SMALLER than the timed one (768 -> 736 sequences = 2 lanes of 368): the same
+    # kernels and lane count, but a launch shape of its own, so that rocprofv3's per-grid summary of this command
+    # (tools/kernel_trace_by_grid.py, profiles/) shows exactly these launches in a row of their own next to `roofline.avg_launch_us`.
+    nl_real = 2 if Bd >= 640 else (3 if Bd >= 144 else (2 if Bd >= 96 else 1))
+    Bp = Bd - 16 * nl_real
+    if (2 if Bp >= 640 else (3 if Bp >= 144 else (2 if Bp >= 96 else 1))) != nl_real or nl_real == 1:
+        Bp = Bd
     os.environ["CCX_NO_GRAPH"] = "1"
     ctx.prof_enable(True)
-    wm.decode_greedy([[rules.sot]] * Bd, sample_len=probe_steps)
+    wm.decode_greedy([[rules.sot]] * Bp, sample_len=probe_steps)
     torch.cuda.synchronize()
     probe = ctx.prof_records()
     ctx.prof_enable(False)
@@ -496,7 +503,10 @@ def main():
         for k, v in pagg.items():
             if k.startswith("dec_") and (v[1] > 0 or v[2] > 0):
                 launches = v[0] / (probe_steps) * decode_steps_per_step
-                per_step[k] = (v[3] / v[0] * launches, f"HIP events, eager re-run of {probe_steps} decode steps of the same batch (graph-resident in the timed region)")
+                # (scaled from the probe's lane size to the timed group's: these kernels' time is proportional to the rows they stream)
+                per_step[k] = (v[3] / v[0] * launches * (Bd / Bp),
+                               f"HIP events on the lanes' streams, eager re-run of {probe_steps} decode steps of a {Bp}-sequence group on the "
+                               f"encoded batch ({nl_real} lane(s); graph-resident in the timed region, where the group has {Bd} sequences)")
         roof = roof_mfma = None
         if per_step:
             name = max(per_step, key=lambda k: per_step[k][0])

@@ -55,6 +55,9 @@ PROTOTYPES = {
     "ccx_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ccx_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
     "ccx_peak_normalize": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _vp]),
+    "ccx_row_variance": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
+    "ccx_cosine_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ccx_speaker_profiles": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ccx_resample_sinc": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),
     "ccx_enc_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ccx_whisper_create": (_i, [_vp, C.POINTER(WhisperDims), _i, C.POINTER(_vp)]),

@@ -43,6 +43,14 @@ class BatchPipeline:
                                                        float(eps), _lib.current_stream_ptr()), "ccx_peak_normalize")
         return y
 
+    def _cos(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """Row-wise cosine similarity of a [R, D] with b [R, D] (or a repeating [b_rows, D]): ccx_cosine_rows."""
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty(a.shape[0], device=a.device, dtype=torch.float32)
+        self.ctx.check(self.ctx.lib.ccx_cosine_rows(self.ctx.handle, a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], b.shape[0],
+                                                    out.data_ptr(), _lib.current_stream_ptr()), "ccx_cosine_rows")
+        return out
+
     def _pad_batch(self, crops: List[torch.Tensor]):
         """Ragged 1-D device crops -> (padded [n, max_len] f32 buffer, lengths).  One gather launch (ccx_gather_rows)
         instead of one copy per crop; columns past a crop's length are uninitialised (the kernels read [:n] only)."""
@@ -119,26 +127,26 @@ class BatchPipeline:
         buf, n = self._pad_batch(crops)
         clean = self._peak(m["denoiser"].reduce_batch(buf, n, self.nra), n, 0.0)
         pe = m["embedding_model"].embed_batch([clean[i, :n[i]] for i in range(len(crops))])
-        # embedding quality = unbiased variance of the raw crop (reference 939): two masked passes over the padded batch
-        # instead of one torch.var launch chain per crop
-        nn = torch.tensor(n, device=buf.device, dtype=torch.float32)
-        msk = torch.arange(buf.shape[1], device=buf.device)[None, :] < nn[:, None]
-        mean = torch.where(msk, buf, 0.0).sum(dim=1) / nn
-        var = torch.where(msk, (buf - mean[:, None]) ** 2, 0.0).sum(dim=1) / (nn - 1.0)
-        # variance-weighted sum of each speaker's turn embeddings (not re-normalised, reference 946-953), all clips at once
-        pe_c, var_c = pe.view(B, len(sched), -1), var.view(B, len(sched))
-        prof_all = {}
-        for spk in ("A", "B"):
-            cols = [j for j, (s_, _, _) in enumerate(sched) if s_ == spk]
-            wts = var_c[:, cols] / var_c[:, cols].sum(dim=1, keepdim=True)
-            prof_all[spk] = (pe_c[:, cols] * wts[..., None]).sum(dim=1)          # [B, D]
+        # embedding quality = unbiased variance of the raw crop (reference 939), then the variance-weighted sum of each speaker's turn
+        # embeddings (not re-normalised, reference 946-953), all clips at once: ccx_row_variance + ccx_speaker_profiles
+        nd = torch.tensor(n, device=buf.device, dtype=torch.int32)
+        var = torch.empty(len(n), device=buf.device, dtype=torch.float32)
+        self.ctx.check(self.ctx.lib.ccx_row_variance(self.ctx.handle, buf.data_ptr(), buf.shape[1], nd.data_ptr(), len(n), var.data_ptr(),
+                                                     _lib.current_stream_ptr()), "ccx_row_variance")
+        D = int(pe.shape[1])
+        pe_c, var_c = pe.view(B, len(sched), D), var.view(B, len(sched))
+        spk_ids = torch.tensor([0 if s_ == "A" else 1 for s_, _, _ in sched], device=buf.device, dtype=torch.int32)
+        prof = torch.empty(B, 2, D, device=buf.device, dtype=torch.float32)
+        self.ctx.check(self.ctx.lib.ccx_speaker_profiles(self.ctx.handle, pe.data_ptr(), var.data_ptr(), spk_ids.data_ptr(), B, len(sched), D, 2,
+                                                         prof.data_ptr(), _lib.current_stream_ptr()), "ccx_speaker_profiles")
+        prof_all = {"A": prof[:, 0], "B": prof[:, 1]}
         profiles = [{spk: prof_all[spk][b] for spk in ("A", "B")} for b in range(B)]
         t = self._mark("profiles", t, timed)
         # 4. regular segments (A 18-24, B 26-30): embed + similarity, then Whisper with the fixed prompt
         reg = [(b, spk, s, e) for b in range(B) for spk, s, e in sched[2:]]
         reg_crops = [den[b, s:e] for b, _, s, e in reg]
         re_ = m["embedding_model"].embed_batch(reg_crops)
-        sims = torch.nn.functional.cosine_similarity(re_, torch.stack([profiles[b][spk] for b, spk, _, _ in reg]), dim=1)
+        sims = self._cos(re_, torch.stack([profiles[b][spk] for b, spk, _, _ in reg]))
         t = self._mark("segment_embed", t, timed)
         # (their Whisper windows are decoded together with the overlap regions' at the end: the calls are independent,
         #  and one large decode batch amortises the latency-bound step chain)
@@ -154,8 +162,7 @@ class BatchPipeline:
         we = m["embedding_model"].embed_batch(wins)
         pa = torch.stack([profiles[ov[i][0]]["A"] for i in owner])
         pb = torch.stack([profiles[ov[i][0]]["B"] for i in owner])
-        win_sims = torch.stack([torch.nn.functional.cosine_similarity(we, pa, dim=1),
-                                torch.nn.functional.cosine_similarity(we, pb, dim=1)], dim=1)   # [windows, 2], one launch
+        win_sims = torch.stack([self._cos(we, pa), self._cos(we, pb)], dim=1)   # [windows, 2]
         t = self._mark("sliding_windows", t, timed)
         # scripted window labels: each overlap segment splits at the scheduled overlap (7-9 s) into two regions
         regions = []
@@ -184,7 +191,8 @@ class BatchPipeline:
             srcs.append(self._peak(sep[:, :, k].contiguous(), rn, 1e-8))
         se = [m["embedding_model"].embed_batch([srcs[k][i, :rn[i]] for i in range(len(rcrops))]) for k in range(2)]
         pr = torch.stack([profiles[b][spk] for b, spk, _, _ in regions])
-        pick = (torch.nn.functional.cosine_similarity(se[1], pr, dim=1) > torch.nn.functional.cosine_similarity(se[0], pr, dim=1)).cpu().tolist()
+        src_sims = torch.stack([self._cos(se[0], pr), self._cos(se[1], pr)], dim=1).cpu()     # [regions, 2]
+        pick = (src_sims[:, 1] > src_sims[:, 0]).tolist()          # strict >: the first source wins a tie (reference 1094-1100)
         best = [srcs[1 if pick[i] else 0][i, :rn[i]] for i in range(len(regions))]
         t = self._mark("source_select", t, timed)
         st = dict(B=B, n_reg=len(reg_crops), whisper_crops=reg_crops + best,
@@ -192,7 +200,7 @@ class BatchPipeline:
                   embeds=len(crops) + len(reg_crops) + len(wins) + 2 * len(rcrops), separator_calls=len(rcrops), sims=sims,
                   win_sims=win_sims, t=t)
         if debug:
-            st["dbg"] = dict(den=den, pe_c=pe_c, var_c=var_c, prof_all=prof_all, owner=owner, sep=sep, rn=rn, se=se, pr=pr, pick=pick,
+            st["dbg"] = dict(den=den, pe_c=pe_c, var_c=var_c, prof_all=prof_all, owner=owner, sep=sep, rn=rn, se=se, pr=pr, pick=pick, src_sims=src_sims,
                              regions=regions, reg=reg, vad_ann=vad_ann, diar_ann=diar_ann)
         return st
 
@@ -212,7 +220,7 @@ class BatchPipeline:
         if debug:
             dbg = dict(den=den.cpu(), profile_embeds=pe_c.cpu(), profile_var=var_c.cpu(), profiles={k: v.cpu() for k, v in prof_all.items()},
                        window_sims_full=win_sims.cpu(), window_owner=list(owner), separated=sep.cpu(), region_len=list(rn),
-                       source_sims=torch.stack([torch.nn.functional.cosine_similarity(se[k], pr, dim=1) for k in range(2)], dim=1).cpu(),
+                       source_sims=d["src_sims"],
                        pick=[int(x) for x in pick], prompt_ids=prompt_ids, whisper_inputs=[c.cpu() for c in reg_crops + best],
                        regions=[(b, spk, s, e) for b, spk, s, e in regions], regular=[(b, spk, s, e) for b, spk, s, e in reg],
                        vad=[[(sg.start, sg.end) for sg, _ in a.itertracks()] for a in d["vad_ann"]],

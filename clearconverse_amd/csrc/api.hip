@@ -106,6 +106,21 @@ int ccx_peak_normalize(ccx_ctx* ctx, const float* x, float* y, int64_t stride, c
   return ccx_launch_peak_normalize(ctx, x, y, (long)stride, n_samples_dev, B, eps, (hipStream_t)stream);
 }
 
+int ccx_row_variance(ccx_ctx* ctx, const float* x, int64_t stride, const int* n_samples_dev, int B, float* out, void* stream) {
+  if (!ctx) return CCX_ERR_ARG;
+  return ccx_launch_row_variance(ctx, x, (long)stride, n_samples_dev, B, out, (hipStream_t)stream);
+}
+
+int ccx_cosine_rows(ccx_ctx* ctx, const float* a, const float* b, int R, int D, int b_rows, float* out, void* stream) {
+  if (!ctx) return CCX_ERR_ARG;
+  return ccx_launch_cosine_rows(ctx, a, b, R, D, b_rows, out, (hipStream_t)stream);
+}
+
+int ccx_speaker_profiles(ccx_ctx* ctx, const float* emb, const float* w, const int* spk_dev, int C, int T, int D, int S, float* out, void* stream) {
+  if (!ctx) return CCX_ERR_ARG;
+  return ccx_launch_speaker_profiles(ctx, emb, w, spk_dev, C, T, D, S, out, (hipStream_t)stream);
+}
+
 int ccx_gather_rows(ccx_ctx* ctx, const int64_t* src_ptrs_dev, const int* lens_dev, int n_rows, int max_len, float* dst_dev,
                     int64_t stride, void* stream) {
   if (!ctx) return CCX_ERR_ARG;

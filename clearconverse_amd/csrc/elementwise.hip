@@ -102,6 +102,97 @@ int ccx_launch_peak_normalize(ccx_ctx* ctx, const float* x, float* y, long strid
   return CCX_OK;
 }
 
+// Unbiased variance of the first n_b samples of every row -- `torch.var(segment_audio)` of the reference's embedding-quality
+// weight (back/api.py:939).  One block per row, two passes (mean, then squared deviations), fp64 accumulators in a FIXED order:
+// the value does not depend on which rows share the launch.  n_b < 2 gives NaN, like torch.
+__global__ __launch_bounds__(1024) void row_variance_kernel(const float* __restrict__ x, long stride, const int* __restrict__ n_samples,
+                                                            float* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ double bc;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = n_samples[b];
+  const float* xr = x + (long)b * stride;
+  auto block_sum = [&](double v) -> double {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < 16; w++) t += red[w];
+      bc = t;
+    }
+    __syncthreads();
+    return bc;
+  };
+  double s = 0.0;
+  for (int i = tid; i < n; i += 1024) s += (double)xr[i];
+  const double mean = block_sum(s) / (double)n;
+  double q = 0.0;
+  for (int i = tid; i < n; i += 1024) { const double d = (double)xr[i] - mean; q += d * d; }
+  const double ss = block_sum(q);
+  if (tid == 0) out[b] = (float)(ss / (double)(n - 1));
+}
+
+int ccx_launch_row_variance(ccx_ctx* ctx, const float* x, long stride, const int* n_samples_dev, int B, float* out, hipStream_t stream) {
+  CCX_REQUIRE(ctx, x && n_samples_dev && out && B >= 1, "row_variance: bad arguments");
+  hipLaunchKernelGGL(row_variance_kernel, dim3(B), dim3(1024), 0, stream, x, stride, n_samples_dev, out);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+// Row-wise cosine similarity, `torch.nn.functional.cosine_similarity(a, b, dim=...)` as ATen computes it since 2.x
+// (reference back/api.py:878-879): sum_i (a_i / max(|a|, eps)) * (b_i / max(|b|, eps)), eps = 1e-8.  b row r = b + (r % b_rows) * D
+// (b_rows < R: every a row against a repeating set of b rows).  One wave per row, fixed reduction tree.
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ a, const float* __restrict__ bm, int R, int D, int b_rows,
+                                                          float eps, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* ar = a + (long)r * D;
+  const float* br = bm + (long)(r % b_rows) * D;
+  float na = 0.f, nb = 0.f;
+  for (int i = lane; i < D; i += 64) { na = fmaf(ar[i], ar[i], na); nb = fmaf(br[i], br[i], nb); }
+  na = fmaxf(sqrtf(wave_reduce_sum(na)), eps);
+  nb = fmaxf(sqrtf(wave_reduce_sum(nb)), eps);
+  float dot = 0.f;
+  for (int i = lane; i < D; i += 64) dot += (ar[i] / na) * (br[i] / nb);
+  dot = wave_reduce_sum(dot);
+  if (lane == 0) out[r] = dot;
+}
+
+int ccx_launch_cosine_rows(ccx_ctx* ctx, const float* a, const float* b, int R, int D, int b_rows, float* out, hipStream_t stream) {
+  CCX_REQUIRE(ctx, a && b && out && R >= 1 && D >= 1 && b_rows >= 1, "cosine_rows: bad arguments");
+  hipLaunchKernelGGL(cosine_rows_kernel, dim3(ccx_cdiv(R, 4)), dim3(256), 0, stream, a, b, R, D, b_rows, 1e-8f, out);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
+// Speaker profiles of the reference's `_build_speaker_profiles` (back/api.py:946-953): per clip c and speaker s the sum of the
+// turn embeddings emb[c][t] of that speaker's turns weighted by w[c][t] / (sum of the speaker's weights) -- not re-normalised.
+// emb [C, T, D], w [C, T], spk [T] (speaker index of turn t, the same for every clip) -> out [C, S, D].  Turns in index order.
+__global__ __launch_bounds__(256) void speaker_profiles_kernel(const float* __restrict__ emb, const float* __restrict__ w,
+                                                               const int* __restrict__ spk, int T, int D, int S, float* __restrict__ out) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  float tot = 0.f;
+  for (int t = 0; t < T; t++) tot += (spk[t] == s) ? w[(long)c * T + t] : 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < T; t++)
+      if (spk[t] == s) acc += emb[((long)c * T + t) * D + i] * (w[(long)c * T + t] / tot);
+    out[((long)c * S + s) * D + i] = acc;
+  }
+}
+
+int ccx_launch_speaker_profiles(ccx_ctx* ctx, const float* emb, const float* w, const int* spk_dev, int C, int T, int D, int S, float* out,
+                                hipStream_t stream) {
+  CCX_REQUIRE(ctx, emb && w && spk_dev && out && C >= 1 && T >= 1 && D >= 1 && S >= 1, "speaker_profiles: bad arguments");
+  hipLaunchKernelGGL(speaker_profiles_kernel, dim3(C, S), dim3(256), 0, stream, emb, w, spk_dev, T, D, S, out);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
 // dst[i][0 .. len_i) = src_i[0 .. len_i): ragged crops (row pointers and lengths in device tables) into a padded batch,
 // one launch instead of one copy per crop.  Columns past len_i are left untouched.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const long* __restrict__ src_ptrs, const int* __restrict__ lens,

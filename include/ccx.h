@@ -63,6 +63,16 @@ int ccx_gather_rows(ccx_ctx* ctx, const int64_t* src_ptrs_dev, const int* lens_d
                     int64_t stride, void* stream);
 int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t stride, const int* n_samples_dev, int B,
                        float eps, void* stream);
+/* Embedding-quality weight of `_build_speaker_profiles`: out[b] = torch.var(x[b][0 .. n_b)) (unbiased; reference back/api.py:939).
+ * fp64 accumulation in a fixed order: a row's value does not depend on its batch mates. */
+int ccx_row_variance(ccx_ctx* ctx, const float* x_dev, int64_t stride, const int* n_samples_dev, int B, float* out_dev, void* stream);
+/* `_calculate_embedding_similarity` (reference back/api.py:878-879: torch cosine_similarity(dim=0).item()), row-wise for a batch:
+ * out[r] = sum_i (a[r][i] / max(|a[r]|, 1e-8)) * (b[r % b_rows][i] / max(|b[..]|, 1e-8)).  a [R, D], b [b_rows, D] f32. */
+int ccx_cosine_rows(ccx_ctx* ctx, const float* a_dev, const float* b_dev, int R, int D, int b_rows, float* out_dev, void* stream);
+/* The weighted sum of `_build_speaker_profiles` (reference back/api.py:946-953): out[c][s] = sum over turns t with spk[t] == s of
+ * emb[c][t] * w[c][t] / (sum of those w[c][t]); NOT re-normalised.  emb [C, T, D], w [C, T], spk_dev [T] int32, out [C, S, D]. */
+int ccx_speaker_profiles(ccx_ctx* ctx, const float* emb_dev, const float* w_dev, const int* spk_dev, int C, int T, int D, int S,
+                         float* out_dev, void* stream);
 
 /* K1: `torchaudio.transforms.Resample(orig_freq=sample_rate, new_freq=16000)(signal)` (reference back/api.py:824-830) with
  * torchaudio's default arguments.  orig / new_ are the two rates divided by their gcd, width = ceil(6 * orig / (min(orig, new_) * 0.99)),

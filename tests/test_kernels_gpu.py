@@ -151,3 +151,52 @@ def test_gather_rows_ragged(ccx_ctx):
     for i, (b, s, n) in enumerate(spans):
         assert torch.equal(dst[i, :n], src[b, s:s + n])
         assert bool((dst[i, n:] == -7.0).all())
+
+
+def test_row_variance_cosine_rows_and_speaker_profiles(ccx_ctx):
+    """The small reductions of the speaker-profile stage (reference back/api.py:939 torch.var, 946-953 weighted sum, 878-879 cosine
+    similarity) through the C ABI, against torch on the host in fp64; a row's result must not depend on its batch mates."""
+    g = torch.Generator().manual_seed(5)
+    lens = [480000, 2, 12345, 144000, 1025, 64000, 7]
+    stride = 480000
+    x = torch.zeros(len(lens), stride)
+    for i, n in enumerate(lens):
+        x[i, :n] = torch.randn(n, generator=g) * (0.05 + 0.1 * i) + (0.3 if i == 2 else 0.0)      # one row with a large mean
+    xd = x.cuda()
+    nd = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    var = torch.empty(len(lens), device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_row_variance(ccx_ctx.handle, xd.data_ptr(), stride, nd.data_ptr(), len(lens), var.data_ptr(), _stream()), "ccx_row_variance")
+    torch.cuda.synchronize()
+    for i, n in enumerate(lens):
+        ref = float(x[i, :n].double().var(unbiased=True))
+        within("row_variance: relative error vs fp64 torch.var", abs(float(var[i]) - ref) / ref, 5e-7, i)
+    one = torch.empty(1, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_row_variance(ccx_ctx.handle, xd[3:4].contiguous().data_ptr(), stride, nd[3:4].contiguous().data_ptr(), 1, one.data_ptr(), _stream()), "ccx_row_variance")
+    assert float(one[0]) == float(var[3])
+    # cosine similarity: own rows, and against a repeating pair of rows
+    a = torch.randn(37, 512, generator=g); b = torch.randn(37, 512, generator=g) * 3.0
+    a[5] = 0.0                                                              # a zero row: 0 / eps -> 0
+    ad, bd = a.cuda(), b.cuda()
+    out = torch.empty(37, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_cosine_rows(ccx_ctx.handle, ad.data_ptr(), bd.data_ptr(), 37, 512, 37, out.data_ptr(), _stream()), "ccx_cosine_rows")
+    ref = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)
+    within("cosine_rows: max abs error vs fp64", float((out.cpu().double() - ref).abs().max()), 5e-7)
+    assert float(out[5]) == 0.0
+    out2 = torch.empty(37, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_cosine_rows(ccx_ctx.handle, ad.data_ptr(), bd.data_ptr(), 37, 512, 2, out2.data_ptr(), _stream()), "ccx_cosine_rows")
+    ref2 = torch.nn.functional.cosine_similarity(a.double(), b[:2].double().repeat(19, 1)[:37], dim=1)
+    assert float((out2.cpu().double() - ref2).abs().max()) < 5e-7
+    sub = torch.empty(3, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_cosine_rows(ccx_ctx.handle, ad[10:13].contiguous().data_ptr(), bd[10:13].contiguous().data_ptr(), 3, 512, 3, sub.data_ptr(), _stream()), "ccx_cosine_rows")
+    assert torch.equal(sub, out[10:13])                                     # bit-identical whatever the batch
+    # speaker profiles: 3 clips x 4 turns (A B A B) x 512
+    emb = torch.randn(3, 4, 512, generator=g); w = torch.rand(3, 4, generator=g) + 0.1
+    spk = torch.tensor([0, 1, 0, 1], dtype=torch.int32)
+    ed, wd, sd = emb.cuda(), w.cuda(), spk.cuda()
+    prof = torch.empty(3, 2, 512, device="cuda")
+    ccx_ctx.check(ccx_ctx.lib.ccx_speaker_profiles(ccx_ctx.handle, ed.data_ptr(), wd.data_ptr(), sd.data_ptr(), 3, 4, 512, 2, prof.data_ptr(), _stream()), "ccx_speaker_profiles")
+    for c in range(3):
+        for s_ in range(2):
+            cols = [t for t in range(4) if int(spk[t]) == s_]
+            ref = sum(emb[c, t].double() * (w[c, t].double() / w[c, cols].double().sum()) for t in cols)
+            assert float((prof[c, s_].cpu().double() - ref).abs().max()) < 1e-6
