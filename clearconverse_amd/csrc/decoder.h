@@ -45,8 +45,16 @@ struct DecAttnParams {
   // prompt prefill: rows (q / out index) != sequences (K/V index).  row_seq [rows] maps them (null: identity); rows_per_seq > 1
   // tells the cross attention that the rows of a sequence are consecutive, so that it can co-schedule them on one XCD
   const int* row_seq; int rows_per_seq;
+  // fused query projection (small batches, ccx_launch_dec_cross_fused_q): q = LN(x + pending slabs) * Wq^T + bq computed by the
+  // attention block itself instead of by a launch of its own.  Wq: the fragment-packed image dec_linear streams.
+  const float* qx; const float* q_pend; int q_pend_n; long q_pend_stride; float* q_x_out;
+  const float* q_ln_g; const float* q_ln_b; float q_eps;
+  const bf16_t* q_W; const float* q_bias; int q_K;
 };
 int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, bool final_out, hipStream_t stream);
+// Cross attention of a small batch (B <= 16 rows) WITH its query projection: replaces ln_linear(Wcq) + ccx_launch_dec_attention(split
+// partials).  Same arithmetic, operation for operation, as the two launches it replaces (q is bit-identical).
+int ccx_launch_dec_cross_fused_q(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, hipStream_t stream);
 
 struct DecSeqState {
   int pos, prompt_len, n_gen, done;

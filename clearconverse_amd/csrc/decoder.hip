@@ -37,6 +37,27 @@ __global__ void dec_embed_kernel(const float* __restrict__ tok_emb, const float*
 }
 
 // ------------------------------------------------------------------------------------------
+// LayerNorm of one residual row, in pieces shared by EVERY decoder kernel that normalises a row (the LN prologue of the skinny
+// linear, the stand-alone resolve + LN, the fused cross-attention query).  Every multiply-add is an explicit fmaf: hipcc has no
+// contraction freedom left, so all of them round alike and a sequence's numbers do not depend on which kernel normalised its row.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ln_add_pend(float4 a, float wgt, const float4 q) {
+  a.x = fmaf(wgt, q.x, a.x); a.y = fmaf(wgt, q.y, a.y); a.z = fmaf(wgt, q.z, a.z); a.w = fmaf(wgt, q.w, a.w);
+  return a;
+}
+__device__ __forceinline__ float ln_sum4(const float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float ln_sq4(const float4 v, float mean) {
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+  return fmaf(d, d, fmaf(c, c, fmaf(b, b, a * a)));
+}
+__device__ __forceinline__ uint2 ln_pack4(const float4 v, float mean, float rstd, const float4 g, const float4 bb) {
+  uint2 o;
+  o.x = pack_bf16x2(fmaf((v.x - mean) * rstd, g.x, bb.x), fmaf((v.y - mean) * rstd, g.y, bb.y));
+  o.y = pack_bf16x2(fmaf((v.z - mean) * rstd, g.z, bb.z), fmaf((v.w - mean) * rstd, g.w, bb.w));
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------
 // Skinny linear
 // ------------------------------------------------------------------------------------------
 // Every kernel of the decode chain is latency-bound (a 768x768 bf16 matrix is 4.6 KB per CU, and a
@@ -172,10 +193,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
           for (int s = 0; s < 4; s++)  // all slab loads issued together (clamped index, masked add)
             q[s] = ((const float4*)(p.pend + (long)(s < p.pend_n ? s : 0) * p.pend_stride + row))[ic];
 #pragma unroll
-          for (int s = 0; s < 4; s++) {
-            const float wgt = s < p.pend_n ? 1.f : 0.f;
-            a.x += wgt * q[s].x; a.y += wgt * q[s].y; a.z += wgt * q[s].z; a.w += wgt * q[s].w;
-          }
+          for (int s = 0; s < 4; s++) a = ln_add_pend(a, s < p.pend_n ? 1.f : 0.f, q[s]);
           if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
           v[u][i] = a;
         }
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
       for (int u = 0; u < 2; u++) {
         float sm = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) sm += (v[u][i].x + v[u][i].y) + (v[u][i].z + v[u][i].w);
+        for (int i = 0; i < 4; i++) sm += ln_sum4(v[u][i]);
         mean[u] = wave_reduce_sum(sm) / (float)K;
       }
 #pragma unroll
@@ -193,8 +211,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const float a = v[u][i].x - mean[u], b = v[u][i].y - mean[u], c = v[u][i].z - mean[u], d = v[u][i].w - mean[u];
-          const float t = a * a + b * b + c * c + d * d;
+          const float t = ln_sq4(v[u][i], mean[u]);
           sq += (lane + 64 * i < nv) ? t : 0.f;
         }
         rstd[u] = rsqrtf(wave_reduce_sum(sq) / (float)K + p.eps);
@@ -207,10 +224,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
         for (int i = 0; i < 4; i++) {
           const int idx = lane + 64 * i;
           if (idx < nv) {
-            uint2 o;
-            o.x = pack_bf16x2((v[u][i].x - mean[u]) * rstd[u] * g[i].x + bb[i].x, (v[u][i].y - mean[u]) * rstd[u] * g[i].y + bb[i].y);
-            o.y = pack_bf16x2((v[u][i].z - mean[u]) * rstd[u] * g[i].z + bb[i].z, (v[u][i].w - mean[u]) * rstd[u] * g[i].w + bb[i].w);
-            *(uint2*)(act_s + (long)r * lds_ld + 4 * idx) = o;
+            *(uint2*)(act_s + (long)r * lds_ld + 4 * idx) = ln_pack4(v[u][i], mean[u], rstd[u], g[i], bb[i]);
             if (writer) ((float4*)(p.x_out + (long)(m0 + r) * K))[idx] = v[u][i];
           }
         }
@@ -367,32 +381,24 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < 4; s++) q[s] = ((const float4*)(pend + (long)(s < pend_n ? s : 0) * pend_stride + (long)m * K))[ic];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const float wgt = s < pend_n ? 1.f : 0.f;
-      a.x += wgt * q[s].x; a.y += wgt * q[s].y; a.z += wgt * q[s].z; a.w += wgt * q[s].w;
-    }
+    for (int s = 0; s < 4; s++) a = ln_add_pend(a, s < pend_n ? 1.f : 0.f, q[s]);
     if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
     v[i] = a;
     if (x_out && idx < nv) ((float4*)(x_out + (long)m * K))[idx] = a;   // resolved residual stream (ping-pong buffer)
-    sm += (a.x + a.y) + (a.z + a.w);
+    sm += ln_sum4(a);
   }
   const float mean = wave_reduce_sum(sm) / (float)K;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const float a = v[i].x - mean, c = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
-    sq += (lane + 64 * i < nv) ? (a * a + c * c + d * d + e * e) : 0.f;
+    const float t = ln_sq4(v[i], mean);
+    sq += (lane + 64 * i < nv) ? t : 0.f;
   }
   const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)K + eps);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int idx = lane + 64 * i;
-    if (idx < nv) {
-      uint2 o;
-      o.x = pack_bf16x2((v[i].x - mean) * rstd * gg[i].x + bb[i].x, (v[i].y - mean) * rstd * gg[i].y + bb[i].y);
-      o.y = pack_bf16x2((v[i].z - mean) * rstd * gg[i].z + bb[i].z, (v[i].w - mean) * rstd * gg[i].w + bb[i].w);
-      ((uint2*)(out + (long)m * K))[idx] = o;
-    }
+    if (idx < nv) ((uint2*)(out + (long)m * K))[idx] = ln_pack4(v[i], mean, rstd, gg[i], bb[i]);
   }
 }
 
@@ -694,6 +700,273 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
       if (tid == 0) { p.part_ml[pbase * 2] = mx; p.part_ml[pbase * 2 + 1] = l; }
     }
   }
+}
+
+// Small-batch cross attention with the query projection inside (B <= 16 rows: the reference's own calling pattern, one file per task
+// and one window per decode, back/api.py:1286-1292).  The decode chain of a small batch is a string of latency-bound launches
+// (~5-7 us each against a ~1 us HBM floor); this removes one of the eight per layer.  A block = (row, head, key split) as in
+// dec_attention_kernel<false>; before it touches q it
+//   1. requests its FIRST 64-key chunk of K and V (they do not depend on q: one HBM round trip now runs under the prologue),
+//   2. requests the 4 x 6 weight fragments of its head's 64 query columns (wave w: k-steps 6 w .. 6 w + 5, the slice the same wave
+//      of dec_linear_kernel<1, 1, 6, ACT_LN, DEPI_F32> owns),
+//   3. normalises its row (every wave for itself into its own LDS row: no barrier) with the shared ln_* pieces,
+//   4. runs the same 24 MFMAs, reduces the four waves' partial sums in the same order (w = 0..3) and adds the bias.
+// Steps 3-4 repeat dec_linear's operations one for one, so q -- and with it every token and log-probability -- is bit-identical
+// to the two-launch path (tests/test_whisper_gpu.py::test_fused_cross_query_equals_two_launches).  K == 768 only (24 k-steps).
+// Register budget: <= 168 VGPRs (three blocks per CU: the 576 blocks of 8 rows x 12 heads x 6 splits are all resident) -- the K chunk
+// (32) and the weight fragments (96) are in flight across the LayerNorm, whose affine parameters are therefore fetched late, and the
+// V chunk is requested only when the MFMAs have freed the weight registers.
+__global__ __launch_bounds__(256, 3) void dec_cross_fused_q_kernel(DecAttnParams p) {
+  __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
+  __shared__ __attribute__((aligned(16))) bf16_t ln_row[4][776];
+  __shared__ __attribute__((aligned(16))) float red[4][4][4][4];     // [wave][n-tile][lane >> 4][4 outputs]: column 0 of every tile
+  __shared__ __attribute__((aligned(16))) float q_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, split = blockIdx.y;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int g = lane >> 3, c = lane & 7;
+  const int T = p.T;
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int kbeg = split * per;
+  const int kend = (kbeg + per < T) ? kbeg + per : T;
+  const int K = p.q_K;                       // 768
+  // block-uniform bases + 32-bit byte offsets per lane (one SGPR pair + one VGPR per address instead of a 64-bit VGPR pair)
+  const char* Ku = (const char*)(p.k + ((long)b * p.H + h) * p.kv_T * 64);
+  const char* Vu = (const char*)(p.v + ((long)b * p.H + h) * p.kv_T * 64);
+  auto kv_off = [&](int key) -> unsigned { return (unsigned)(key * 64 + 8 * c) * 2u; };
+
+  // vmcnt retires IN ORDER, so whatever the LayerNorm waits for must be requested BEFORE the long HBM round trip of the K chunk:
+  // ---- 1. the row, its pending split-K slabs and the LayerNorm's affine parameters (L2 hits) ----
+  const int nv = K >> 2;
+  const long row = (long)b * K;
+  float4 v[4], pq[4], gg[4], bb[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    const int ic = idx < nv ? idx : 0;
+    const unsigned o16 = (unsigned)ic * 16u;
+    v[i] = *(const float4*)((const char*)(p.qx + row) + o16);
+    // (dec_linear adds all four slab slots, the unused ones with weight 0: fmaf(0, finite, a) == a, so skipping them is bit-identical;
+    //  two or more pending slabs take the generic loop below)
+    pq[i] = *(const float4*)((const char*)(p.q_pend + row) + o16);
+    gg[i] = *(const float4*)((const char*)p.q_ln_g + o16);
+    bb[i] = *(const float4*)((const char*)p.q_ln_b + o16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 2. first K chunk of this wave (clamped like the loop below: a wave without keys loads row kend - 1 and masks it) ----
+  bf16x8 kf[8], vf[8];
+  {
+    const int base = kbeg + wave * 64;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      int key = base + it * 8 + g;
+      key = key < kend ? key : kend - 1;
+      kf[it] = __builtin_nontemporal_load((const bf16x8*)(Ku + kv_off(key)));
+    }
+  }
+  // ---- 3. weight fragments: n-tiles 4 h .. 4 h + 3, k-steps 6 wave .. 6 wave + 5 (packed image: tile (n / 16, k / 32) = 1 KB), in three
+  // groups of two k-steps (32 registers each, at most two groups in flight).  Default cache policy: the 48 blocks of a head share them.
+  const int ksteps = K >> 5;                 // 24
+  const int ks0 = wave * 6;
+  const char* wu = (const char*)(p.q_W + ((long)(4 * h) * ksteps + ks0) * 512);       // block- and wave-uniform
+  auto load_group = [&](int gk, bf16x8 (&w)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int k = 0; k < 2; k++) w[i][k] = *(const bf16x8*)(wu + (unsigned)(((i * ksteps + 2 * gk + k) * 64 + lane) * 16));
+  };
+  bf16x8 wa[4][2], wb[4][2];
+  load_group(0, wa);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- 4. LayerNorm of row b (x + pending slabs), every wave for itself ----
+  {
+    const bool writer = (h == 0 && split == 0 && wave == 0 && p.q_x_out != nullptr);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int idx = lane + 64 * i;
+      const int ic = idx < nv ? idx : 0;
+      float4 a = v[i];
+      a = ln_add_pend(a, p.q_pend_n > 0 ? 1.f : 0.f, pq[i]);
+      for (int s = 1; s < p.q_pend_n; s++)       // (rare: only K > 1024 producers leave more than one slab)
+        a = ln_add_pend(a, 1.f, ((const float4*)(p.q_pend + (long)s * p.q_pend_stride + row))[ic]);
+      if (idx >= nv) a = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = a;
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) sm += ln_sum4(v[i]);
+    const float mean = wave_reduce_sum(sm) / (float)K;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float t = ln_sq4(v[i], mean);
+      sq += (lane + 64 * i < nv) ? t : 0.f;
+    }
+    const float rstd = rsqrtf(wave_reduce_sum(sq) / (float)K + p.q_eps);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int idx = lane + 64 * i;
+      if (idx < nv) {
+        *(uint2*)(&ln_row[wave][4 * idx]) = ln_pack4(v[i], mean, rstd, gg[i], bb[i]);
+        if (writer) ((float4*)(p.q_x_out + row))[idx] = v[i];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_group(1, wb);
+  // the wave's own LDS row: its stores are complete once lgkmcnt is 0, no other wave reads it
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // ---- 5. q = row * Wq^T: the activation fragment is the same row in every MFMA column; k-steps in the order 0..5 ----
+  float4 bias4;
+  {
+    const int h4 = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma_group = [&](int gk, const bf16x8 (&w)[4][2]) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const bf16x8 af = *(const bf16x8*)(&ln_row[wave][8 * h4 + 32 * (ks0 + 2 * gk + k)]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][k], af, acc[i], 0, 0, 0);
+      }
+    };
+    mma_group(0, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    load_group(2, wa);
+    bias4 = *(const float4*)(p.q_bias + h * 64 + 4 * (tid & 15));     // (no branch around the load: hipcc would wait at it)
+    // first V chunk behind the last weight group (its HBM round trip runs under the remaining MFMAs, the reduction and q . k)
+    {
+      const int base = kbeg + wave * 64;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        int key = base + it * 8 + g;
+        key = key < kend ? key : kend - 1;
+        vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vu + kv_off(key)));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_group(1, wb);
+    mma_group(2, wa);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) *(f32x4*)(&red[wave][i][h4][0]) = acc[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    // thread t finishes outputs 4 t .. 4 t + 3 of the head: n-tile t >> 2, rows 4 (t & 3) .. + 3; waves summed in the order 0..3
+    const int i = tid >> 2, r4 = tid & 3;
+    f32x4 v = *(const f32x4*)(&red[0][i][r4][0]);
+#pragma unroll
+    for (int w = 1; w < 4; w++) v += *(const f32x4*)(&red[w][i][r4][0]);
+    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
+    *(float4*)(&q_s[4 * tid]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+  float q[8];
+  {
+    const float4 a = *(const float4*)(&q_s[8 * c]), d = *(const float4*)(&q_s[8 * c + 4]);
+    q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = d.x; q[5] = d.y; q[6] = d.z; q[7] = d.w;
+  }
+
+  // ---- attention over this block's keys: dec_attention_kernel<false>'s loop, its first chunk already in registers ----
+  float sm = -1e30f, sl = 0.f, so[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) so[j] = 0.f;
+  for (int base = kbeg + wave * 64; base < kend; base += 256) {
+    if (base != kbeg + wave * 64) {
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        int key = base + it * 8 + g;
+        key = key < kend ? key : kend - 1;
+        kf[it] = __builtin_nontemporal_load((const bf16x8*)(Ku + kv_off(key)));
+        vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vu + kv_off(key)));
+      }
+    }
+    float s[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; j++) a = fmaf(q[j], bf16_to_f32((bf16_t)kf[it][j]), a);
+      a = group8_sum(a) * p.scale_log2e;
+      s[it] = (base + it * 8 + g < kend) ? a : -INFINITY;
+    }
+    float mn = sm;
+#pragma unroll
+    for (int it = 0; it < 8; it++) mn = fmaxf(mn, s[it]);
+    const float al = __builtin_amdgcn_exp2f(sm - mn);
+    sl *= al;
+#pragma unroll
+    for (int j = 0; j < 8; j++) so[j] *= al;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const float pe = __builtin_amdgcn_exp2f(s[it] - mn);
+      sl += pe;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[j] = fmaf(pe, bf16_to_f32((bf16_t)vf[it][j]), so[j]);
+    }
+    sm = mn;
+  }
+  {
+    auto merge_with = [&](float om, float ol, const float (&oo)[8]) {
+      const float mx = fmaxf(sm, om);
+      const float wa = __builtin_amdgcn_exp2f(sm - mx), wb = __builtin_amdgcn_exp2f(om - mx);
+      sl = sl * wa + ol * wb;
+#pragma unroll
+      for (int j = 0; j < 8; j++) so[j] = so[j] * wa + oo[j] * wb;
+      sm = mx;
+    };
+    float om, ol, oo[8];
+    om = dpp_mov<0x128>(sm); ol = dpp_mov<0x128>(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = dpp_mov<0x128>(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor16(sm); ol = lane_xor16(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor16(so[j]);
+    merge_with(om, ol, oo);
+    om = lane_xor32(sm); ol = lane_xor32(sl);
+#pragma unroll
+    for (int j = 0; j < 8; j++) oo[j] = lane_xor32(so[j]);
+    merge_with(om, ol, oo);
+  }
+  if (g == 0) {
+    sm_m[wave][c] = sm; sm_l[wave][c] = sl;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sm_o[wave][c][j] = so[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int cc = tid >> 3, j = tid & 7;
+    float mx = fmaxf(fmaxf(sm_m[0][cc], sm_m[1][cc]), fmaxf(sm_m[2][cc], sm_m[3][cc]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float ww = __builtin_amdgcn_exp2f(sm_m[w][cc] - mx);
+      l += ww * sm_l[w][cc];
+      o += ww * sm_o[w][cc][j];
+    }
+    const long pbase = ((long)b * p.H + h) * gridDim.y + split;
+    p.part_o[pbase * 64 + tid] = o;
+    if (tid == 0) { p.part_ml[pbase * 2] = mx; p.part_ml[pbase * 2 + 1] = l; }
+  }
+}
+
+int ccx_launch_dec_cross_fused_q(ccx_ctx* ctx, const DecAttnParams& p, int B, int nsplit, hipStream_t stream) {
+  CCX_REQUIRE(ctx, B > 0 && B <= 16 && p.H > 0 && nsplit >= 1 && nsplit <= 8, "dec_cross_fused_q: bad shape");
+  CCX_REQUIRE(ctx, p.q_K == 768 && p.H * 64 == p.q_K && !p.pos && !p.row_seq, "dec_cross_fused_q: needs d_model 768 and one row per sequence");
+  CCX_REQUIRE(ctx, p.qx && p.q_W && p.q_bias && p.q_ln_g && p.q_ln_b && p.q_pend && p.q_pend_n >= 0 && p.q_pend_n <= 4, "dec_cross_fused_q: missing operands");
+  CCX_REQUIRE(ctx, p.q_x_out != p.qx, "dec_cross_fused_q: x_out must not alias x");
+  {
+    // algorithmic bytes: the K/V of the batch once + the query weights once
+    ccx_prof_scope ps(ctx, stream, "dec_cross_fused_q_kernel", 4.0 * B * p.H * (double)p.T * 64 + 2.0 * B * (double)p.q_K * p.q_K,
+                      (double)B * p.H * p.T * 64 * 2 * 2 + 2.0 * p.q_K * p.q_K);
+    hipLaunchKernelGGL(dec_cross_fused_q_kernel, dim3(B * p.H, nsplit), dim3(256), 0, stream, p);
+  }
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
 }
 
 // Cross attention for decode lanes that overlap other lanes' latency-bound chains ("lean streaming").  The chain kernels of

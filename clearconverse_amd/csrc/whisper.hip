@@ -131,6 +131,7 @@ struct ccx_whisper {
   static constexpr int kMaxLanes = 4;
   int cross_lds_pad = 0;                     // see ccx_whisper_decode: occupancy cap of the cross-attention blocks while lanes overlap
   int cross_stream = 0;                      // 1: lean-streaming cross attention (dec_cross_stream_kernel) for batches > 16
+  int fuse_cross_q = 1;                      // 1: batches <= 16 compute the cross-attention query inside the attention blocks
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
                                              // queue run strictly one after the other, so lanes are picked by a probe
@@ -964,8 +965,11 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     stamp(17, 2);
     TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
     stamp(18, 2);
-    // cross attention
-    TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
+    // cross attention.  Small batches (<= 16 rows, d_model 768: the reference's one-window-per-call pattern): the query projection
+    // LN(x) Wcq^T runs INSIDE the cross-attention blocks (ccx_launch_dec_cross_fused_q: one launch fewer per layer on a chain that
+    // is latency-bound launch by launch; q is bit-identical to the two-launch path).  CCX_FUSE_CROSS_Q=0 restores the two launches.
+    const bool fuse_q = w->fuse_cross_q && !pre && B <= 16 && D == 768 && ablate == 0;
+    if (!fuse_q) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     memset(&ap, 0, sizeof(ap));
@@ -973,7 +977,13 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
     ap.lds_pad = w->cross_lds_pad;
     ap.stream_mode = (w->cross_stream && B > 16) ? 1 : 0;
-    if (pre) {
+    if (fuse_q) {
+      ap.qx = cur; ap.q_pend = pend; ap.q_pend_n = pend_n; ap.q_pend_stride = pstride; ap.q_x_out = pend_n > 0 ? other : nullptr;
+      ap.q_ln_g = L.lnc_g; ap.q_ln_b = L.lnc_b; ap.q_eps = 1e-5f; ap.q_W = L.Wcq; ap.q_bias = L.bcq; ap.q_K = D;
+      TRY(ccx_launch_dec_cross_fused_q(ctx, ap, B, ns, stream));
+      if (pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
+      TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
+    } else if (pre) {
       ap.row_seq = row_seq; ap.rows_per_seq = prefill_rows; ap.lds_pad = 0; ap.stream_mode = 1;
       if (prefill_rows > 1) {
         TRY(ccx_launch_dec_attention(ctx, ap, nseq, 1, true, stream));
@@ -1188,6 +1198,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     static const int forced_pad = [] { const char* e = getenv("CCX_CROSS_LDS_PAD"); return e ? atoi(e) : -1; }();
     static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 1; }();
     w->cross_stream = lean;
+    { const char* e = getenv("CCX_FUSE_CROSS_Q"); w->fuse_cross_q = e ? (atoi(e) != 0) : 1; }      // read per decode: tests flip it
     // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight.  The claim only exists to
     // leave room for the OTHER lanes' chain kernels: a single lane runs uncapped.
     w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? (lean ? 98304 : 65536) : 0);
@@ -1234,7 +1245,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream, i};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4), i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

@@ -251,6 +251,44 @@ def test_sampling_is_independent_of_batch_split(ccx_ctx, monkeypatch):
     assert [r["tokens"] for r in a] == [r["tokens"] for r in b]
 
 
+def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
+    """Batches of <= 16 sequences compute the cross-attention query INSIDE the cross-attention blocks (dec_cross_fused_q_kernel: the
+    reference's own pattern is one window per decode, back/api.py:1286-1292).  It repeats the two launches it replaces operation
+    for operation, so at full small.en size the tokens, log-probabilities and no-speech probabilities of 1, 5 and 16 sequences
+    (prompts of different lengths, stepwise prompt feeding and prefill, greedy and sampled) must equal the two-launch path exactly;
+    a 20-sequence batch (large-batch path, never fused) decodes the same tokens for the same windows."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.small_en()
+    sd = synthetic_whisper_state_dict(dims, seed=3, gain=3.0)
+    m = WhisperModel(dims, sd, max_batch=20, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([30.0, 9.0, 4.0, 17.5, 2.0] * 4)
+        m.log_mel(dev, n)
+        m.encode(20)
+        base = [[rules.sot], [rules.sot_prev, 1212, 318, rules.sot], [rules.sot_prev, 464, 1917, 11, 262, rules.sot], [rules.sot], [rules.sot_prev, 50, rules.sot]]
+        for B in (1, 5, 16):
+            prompts = [base[i % 5] for i in range(B)]
+            for kw in (dict(temperature=0.0), dict(temperature=0.7, seed=11)):
+                monkeypatch.setenv("CCX_FUSE_CROSS_Q", "0")
+                two = m.decode(prompts, sample_len=7, **kw)
+                monkeypatch.setenv("CCX_FUSE_CROSS_Q", "1")
+                one = m.decode(prompts, sample_len=7, **kw)
+                again = m.decode(prompts, sample_len=7, **kw)          # replays the captured step graph
+                for a, b, c in zip(two, one, again):
+                    assert a["tokens"] == b["tokens"] == c["tokens"] and len(b["tokens"]) > 0
+                    assert a["sum_logprob"] == b["sum_logprob"] == c["sum_logprob"], (B, kw, a["sum_logprob"], b["sum_logprob"])
+                    assert a["no_speech_prob"] == b["no_speech_prob"]
+        monkeypatch.setenv("CCX_FUSE_CROSS_Q", "1")
+        small = m.decode([base[i % 5] for i in range(16)], sample_len=7)
+        large = m.decode([base[i % 5] for i in range(20)], sample_len=7)
+        for i in range(16):
+            assert small[i]["tokens"] == large[i]["tokens"], i
+            assert abs(small[i]["sum_logprob"] - large[i]["sum_logprob"]) < 2e-3 * max(1.0, abs(large[i]["sum_logprob"])), i
+    finally:
+        m.close()
+
+
 def test_small_en_full_size(ccx_ctx):
     """Full small.en dimensions (the BASELINE architecture), B=2, encoder + short greedy decode."""
     from clearconverse_amd.whisper import WhisperModel
