@@ -63,7 +63,7 @@ def test_separator_short_and_ragged(ccx_ctx):
     orc = S.SepformerRef(S.SepDims(**dims.__dict__), sd)
     ref = orc.separate(mix[1:2, :40].cpu())
     got = out[1:2, :40].cpu()
-    within("sepformer 2-layer: 40-sample utterance rel-L2", float((got - ref).norm() / (ref.norm() + 1e-9)), 5e-2)
+    within("sepformer 2-layer: 40-sample utterance rel-L2", float((got - ref).norm() / (ref.norm() + 1e-9)), 1e-2)
     with pytest.raises(_lib.CcxError):
         sep.separate_batch(mix, [4000, 0, 10])                             # an empty utterance is an error, not a crash
 

@@ -103,7 +103,7 @@ def test_layernorm(ccx_ctx, M, D):
                                    ob.data_ptr(), of.data_ptr(), M, D, 1e-5, _stream())
     ccx_ctx.check(rc, "layernorm")
     torch.cuda.synchronize()
-    within("layernorm_kernel: fp32 output max abs error", float((of.cpu() - ref).abs().max()), 2e-5)
+    within("layernorm_kernel: fp32 output max abs error", float((of.cpu() - ref).abs().max()), 3e-6)
     assert float((ob.float().cpu() - ref).abs().max()) < 0.03
 
 
@@ -169,7 +169,7 @@ def test_row_variance_cosine_rows_and_speaker_profiles(ccx_ctx):
     torch.cuda.synchronize()
     for i, n in enumerate(lens):
         ref = float(x[i, :n].double().var(unbiased=True))
-        within("row_variance: relative error vs fp64 torch.var", abs(float(var[i]) - ref) / ref, 5e-7, i)
+        within("row_variance: relative error vs fp64 torch.var", abs(float(var[i]) - ref) / ref, 1.2e-7, i)
     one = torch.empty(1, device="cuda")
     ccx_ctx.check(ccx_ctx.lib.ccx_row_variance(ccx_ctx.handle, xd[3:4].contiguous().data_ptr(), stride, nd[3:4].contiguous().data_ptr(), 1, one.data_ptr(), _stream()), "ccx_row_variance")
     assert float(one[0]) == float(var[3])
@@ -180,7 +180,7 @@ def test_row_variance_cosine_rows_and_speaker_profiles(ccx_ctx):
     out = torch.empty(37, device="cuda")
     ccx_ctx.check(ccx_ctx.lib.ccx_cosine_rows(ccx_ctx.handle, ad.data_ptr(), bd.data_ptr(), 37, 512, 37, out.data_ptr(), _stream()), "ccx_cosine_rows")
     ref = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=1)
-    within("cosine_rows: max abs error vs fp64", float((out.cpu().double() - ref).abs().max()), 5e-7)
+    within("cosine_rows: max abs error vs fp64", float((out.cpu().double() - ref).abs().max()), 6e-8)
     assert float(out[5]) == 0.0
     out2 = torch.empty(37, device="cuda")
     ccx_ctx.check(ccx_ctx.lib.ccx_cosine_rows(ccx_ctx.handle, ad.data_ptr(), bd.data_ptr(), 37, 512, 2, out2.data_ptr(), _stream()), "ccx_cosine_rows")

@@ -28,7 +28,7 @@ def test_matches_oracle(ccx_ctx, seconds, prop):
         ref = reduce_noise(x, 16000, prop)
         assert got.shape == ref.shape and got.dtype == np.float32
         assert np.isfinite(got).all()
-        within("spectral gate: denoised clip rel-L2", _rel(got, ref), 2e-3)
+        within("spectral gate: denoised clip rel-L2", _rel(got, ref), 5e-7)
     finally:
         g.close()
 
@@ -61,8 +61,8 @@ def test_long_signal_chunked_path_matches_oracle(ccx_ctx, seconds):
         got = g(x, 16000, 0.5)
         ref = reduce_noise(x, 16000, 0.5)
         assert got.shape == ref.shape
-        within("spectral gate (chunked, > 37.5 s): denoised signal rel-L2", _rel(got, ref), 2e-3)
+        within("spectral gate (chunked, > 37.5 s): denoised signal rel-L2", _rel(got, ref), 1e-5)
         for seam in range(600000, n, 600000):              # no discontinuity at a chunk seam
-            within("spectral gate (chunked): rel-L2 of 4000 samples around a chunk seam", _rel(got[seam - 2000:seam + 2000], ref[seam - 2000:seam + 2000]), 5e-3)
+            within("spectral gate (chunked): rel-L2 of 4000 samples around a chunk seam", _rel(got[seam - 2000:seam + 2000], ref[seam - 2000:seam + 2000]), 5e-7)
     finally:
         g.close()

@@ -160,8 +160,8 @@ def _check_greedy(dims, sd, m, xa, prompts, sample_len, tol):
                 assert t == int(lg.argmax())
                 n_exact_required += 1
             seq.append(t); sampled.append(t)
-        within("whisper greedy: |sum_logprob - oracle (teacher forced)| / max(1, |oracle|)", abs(o.sum_logprob - r["sum_logprob"]) / max(1.0, abs(o.sum_logprob)), 0.05 + tol * len(forced) / max(1.0, abs(o.sum_logprob)))
-        within("whisper greedy: |no_speech_prob - oracle|", abs(o.no_speech_prob - r["no_speech_prob"]), 1e-3 + 0.05 * o.no_speech_prob)
+        within("whisper greedy: |sum_logprob - oracle (teacher forced)| / max(1, |oracle|)", abs(o.sum_logprob - r["sum_logprob"]) / max(1.0, abs(o.sum_logprob)), 1.5e-3)
+        within("whisper greedy: |no_speech_prob - oracle|", abs(o.no_speech_prob - r["no_speech_prob"]), 1e-6 + 1e-3 * o.no_speech_prob)
     return res, n_exact_required
 
 
@@ -284,7 +284,10 @@ def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
         large = m.decode([base[i % 5] for i in range(20)], sample_len=7)
         for i in range(16):
             assert small[i]["tokens"] == large[i]["tokens"], i
-            assert abs(small[i]["sum_logprob"] - large[i]["sum_logprob"]) < 2e-3 * max(1.0, abs(large[i]["sum_logprob"])), i
+            # (gain-3 weights: sharper softmaxes than the other path-equivalence tests, whose bound is 2e-3; 6 split-KV partials against
+            #  one block per key range -- the same two kernels as before the fusion)
+            within("whisper small.en gain 3: |sum_logprob small-batch - large-batch path| / max(1, |.|)",
+                   abs(small[i]["sum_logprob"] - large[i]["sum_logprob"]) / max(1.0, abs(large[i]["sum_logprob"])), 5e-3, i)
     finally:
         m.close()
 
