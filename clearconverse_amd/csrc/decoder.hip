@@ -713,10 +713,12 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(DecAttnParams p) {
 //   4. runs the same 24 MFMAs, reduces the four waves' partial sums in the same order (w = 0..3) and adds the bias.
 // Steps 3-4 repeat dec_linear's operations one for one, so q -- and with it every token and log-probability -- is bit-identical
 // to the two-launch path (tests/test_whisper_gpu.py::test_fused_cross_query_equals_two_launches).  K == 768 only (24 k-steps).
-// Register budget: <= 168 VGPRs (three blocks per CU: the 576 blocks of 8 rows x 12 heads x 6 splits are all resident) -- the K chunk
-// (32) and the weight fragments (96) are in flight across the LayerNorm, whose affine parameters are therefore fetched late, and the
-// V chunk is requested only when the MFMAs have freed the weight registers.
-__global__ __launch_bounds__(256, 3) void dec_cross_fused_q_kernel(DecAttnParams p) {
+// Register budget.  EARLY_V = false: <= 168 VGPRs (three blocks per CU, so that the 576 blocks of 8 rows x 12 heads x 6 splits are all
+// resident): the K chunk (32) and two weight groups (64) are in flight across the LayerNorm (64) and the V chunk is requested only when
+// the first MFMAs have freed a weight group -- its HBM round trip is then partly exposed.  EARLY_V = true (grids of <= 512 blocks, i.e.
+// up to 7 rows: two blocks per CU hold them all): V is requested right behind K, 32 registers more.
+template <bool EARLY_V>
+__global__ __launch_bounds__(256, EARLY_V ? 2 : 3) void dec_cross_fused_q_kernel(DecAttnParams p) {
   __shared__ float sm_m[4][8], sm_l[4][8], sm_o[4][8][8];
   __shared__ __attribute__((aligned(16))) bf16_t ln_row[4][776];
   __shared__ __attribute__((aligned(16))) float red[4][4][4][4];     // [wave][n-tile][lane >> 4][4 outputs]: column 0 of every tile
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_fused_q_kernel(DecAttnParams
       int key = base + it * 8 + g;
       key = key < kend ? key : kend - 1;
       kf[it] = __builtin_nontemporal_load((const bf16x8*)(Ku + kv_off(key)));
+      if (EARLY_V) vf[it] = __builtin_nontemporal_load((const bf16x8*)(Vu + kv_off(key)));
     }
   }
   // ---- 3. weight fragments: n-tiles 4 h .. 4 h + 3, k-steps 6 wave .. 6 wave + 5 (packed image: tile (n / 16, k / 32) = 1 KB), in three
@@ -836,7 +839,7 @@ __global__ __launch_bounds__(256, 3) void dec_cross_fused_q_kernel(DecAttnParams
     load_group(2, wa);
     bias4 = *(const float4*)(p.q_bias + h * 64 + 4 * (tid & 15));     // (no branch around the load: hipcc would wait at it)
     // first V chunk behind the last weight group (its HBM round trip runs under the remaining MFMAs, the reduction and q . k)
-    {
+    if (!EARLY_V) {
       const int base = kbeg + wave * 64;
 #pragma unroll
       for (int it = 0; it < 8; it++) {
@@ -963,7 +966,8 @@ int ccx_launch_dec_cross_fused_q(ccx_ctx* ctx, const DecAttnParams& p, int B, in
     // algorithmic bytes: the K/V of the batch once + the query weights once
     ccx_prof_scope ps(ctx, stream, "dec_cross_fused_q_kernel", 4.0 * B * p.H * (double)p.T * 64 + 2.0 * B * (double)p.q_K * p.q_K,
                       (double)B * p.H * p.T * 64 * 2 * 2 + 2.0 * p.q_K * p.q_K);
-    hipLaunchKernelGGL(dec_cross_fused_q_kernel, dim3(B * p.H, nsplit), dim3(256), 0, stream, p);
+    if (B * p.H * nsplit <= 512) hipLaunchKernelGGL(dec_cross_fused_q_kernel<true>, dim3(B * p.H, nsplit), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(dec_cross_fused_q_kernel<false>, dim3(B * p.H, nsplit), dim3(256), 0, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
