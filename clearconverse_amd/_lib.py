@@ -95,6 +95,7 @@ PROTOTYPES = {
     "ccx_specgate_destroy": (None, [_vp]),
     "ccx_specgate_reduce": (_i, [_vp, _vp, _i64, _ip, _i, _f, _vp, _vp]),
     "ccx_specgate_reduce_long": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    "ccx_specgate_set_clip_noise": (_i, [_vp, _i]),
 }
 
 _lib: Optional[C.CDLL] = None

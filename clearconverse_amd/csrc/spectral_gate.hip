@@ -243,6 +243,7 @@ struct ccx_specgate {
   float2* X = nullptr;
   int *n_dev = nullptr, *nf_noise = nullptr, *nf_sig = nullptr;
   long* origin = nullptr;          // reduce_long: first sample of each chunk
+  int clip_noise = 1;              // reduce_long: noise statistics from the first 600000 samples only (noisereduce's clip_noise_stationary)
 };
 
 namespace {
@@ -357,9 +358,17 @@ int ccx_specgate_reduce(ccx_specgate* g, const float* y, int64_t stride, const i
 }
 
 // One signal of any length the workspace holds: noisereduce's chunked path (chunk_size 600000, padding 30000).  The threshold
-// comes from the WHOLE signal (its noise statistics are taken over y itself); every 600000-sample chunk is then gated on its
-// own -- padded with 30000 real neighbour samples on each side (zeros beyond the ends of the signal), its dB floor (max - 80)
+// comes from the noise clip, which is the signal itself (y_noise = None) -- cut to its FIRST chunk_size samples when
+// clip_noise_stationary is on (noisereduce's default; ccx_specgate_set_clip_noise(g, 0) takes the whole signal instead: the package
+// is not importable here and the reference holds no fixture, so which of the two upstream does is parity unpinned) --; every
+// 600000-sample chunk is then gated on its own -- padded with 30000 real neighbour samples on each side (zeros beyond the ends of the signal), its dB floor (max - 80)
 // taken per chunk -- and only the chunk's own samples are written.  Chunks are processed as the "clips" of the batched kernels.
+int ccx_specgate_set_clip_noise(ccx_specgate* g, int on) {
+  if (!g) return CCX_ERR_ARG;
+  g->clip_noise = on ? 1 : 0;
+  return CCX_OK;
+}
+
 int ccx_specgate_reduce_long(ccx_specgate* g, const float* y, int64_t n, float prop_decrease, float* out, void* stream_) {
   if (!g) return CCX_ERR_ARG;
   ccx_ctx* ctx = g->ctx;
@@ -372,8 +381,10 @@ int ccx_specgate_reduce_long(ccx_specgate* g, const float* y, int64_t n, float p
   CCX_REQUIRE(ctx, nfn <= R && rows_c <= R, "specgate_reduce_long: %ld samples need %ld frame rows, the workspace holds %ld (max_samples x max_clips)", (long)n, nfn > rows_c ? nfn : rows_c, R);
   CCX_REQUIRE(ctx, n < (1L << 31) - CH, "specgate_reduce_long: signal too long");
   if (!g->origin) GTRY(galloc(g, &g->origin, (size_t)g->max_clips));
-  // ---- threshold from the whole signal (one "clip" that owns all rows) ----
-  const int n_i = (int)n, nfn_i = (int)nfn;
+  // ---- threshold from the noise clip = the signal itself, cut to its first chunk when clip_noise_stationary is on (one "clip" that
+  // owns all rows) ----
+  const long n_noise = (g->clip_noise && n > CH) ? CH : n;
+  const int n_i = (int)n_noise, nfn_i = (int)(1 + n_noise / SG_HOP);
   CCX_HIP(ctx, hipMemcpyAsync(g->n_dev, &n_i, 4, hipMemcpyHostToDevice, st));
   CCX_HIP(ctx, hipMemcpyAsync(g->nf_noise, &nfn_i, 4, hipMemcpyHostToDevice, st));
   CCX_HIP(ctx, hipStreamSynchronize(st));

@@ -15,7 +15,7 @@ from . import _lib
 
 class SpectralGate:
     def __init__(self, max_samples: int = 480000, max_clips: int = 32, sample_rate: int = 16000, device: int = 0,
-                 ctx: Optional[_lib.Context] = None):
+                 ctx: Optional[_lib.Context] = None, clip_noise_stationary: bool = True):
         if not torch.cuda.is_available():
             raise _lib.CcxError("SpectralGate needs a ROCm GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -26,6 +26,10 @@ class SpectralGate:
         self.ctx.check(self.lib.ccx_specgate_create(self.ctx.handle, self.max_samples, self.max_clips, self.sr, C.byref(h)),
                        "ccx_specgate_create")
         self.handle = h
+        # signals beyond one 600000-sample chunk: noise statistics from the first chunk only (noisereduce's clip_noise_stationary=True,
+        # its default) or from the whole signal (False).  One switch, parity unpinned -- see ccx.h
+        self.clip_noise_stationary = bool(clip_noise_stationary)
+        self.ctx.check(self.lib.ccx_specgate_set_clip_noise(self.handle, 1 if clip_noise_stationary else 0), "ccx_specgate_set_clip_noise")
 
     def close(self):
         if getattr(self, "handle", None):

@@ -248,8 +248,12 @@ void ccx_specgate_destroy(ccx_specgate* g);
 /* y_dev [B, stride] f32, n_samples host [B] -> out_dev [B, stride] f32 (samples past n_samples[b] are zero) */
 int ccx_specgate_reduce(ccx_specgate* g, const float* y_dev, int64_t stride, const int* n_samples, int B,
                         float prop_decrease, float* out_dev, void* stream);
+/* noisereduce's `clip_noise_stationary` (default on): the noise statistics of ccx_specgate_reduce_long come from the first 600000
+ * samples of the signal only (y_noise = y clipped to chunk_size); 0 = from the whole signal.  Parity unpinned (no fixture, the
+ * package is not importable): [UPSTREAM-RECALL] says the clip is applied when the signal stands in for the noise clip as well. */
+int ccx_specgate_set_clip_noise(ccx_specgate* g, int on);
 /* One signal of ANY length (device pointers): noisereduce's chunked path for inputs beyond its chunk_size of 600000 samples --
- * threshold from the whole signal, then each 600000-sample chunk gated with 30000 samples of real context on either side
+ * threshold from the noise clip (see above), then each 600000-sample chunk gated with 30000 samples of real context on either side
  * (the reference passes whole files to nr.reduce_noise, back/api.py:832-833).  Capacity: n / 256 + 1 <= frame rows of the
  * workspace = (max_samples + 60000) / 256 + 2 per clip x max_clips.  y_dev and out_dev must not overlap. */
 int ccx_specgate_reduce_long(ccx_specgate* g, const float* y_dev, int64_t n, float prop_decrease, float* out_dev, void* stream);

@@ -65,12 +65,15 @@ def _filter_chunk(y: np.ndarray, start: int, end: int, thresh: np.ndarray, sr: i
     return out[PADDING:PADDING + (end - start)]
 
 
-def reduce_noise(y: np.ndarray, sr: int = 16000, prop_decrease: float = 1.0, n_std: float = 1.5) -> np.ndarray:
-    """Any length: signals beyond CHUNK samples are filtered chunk by chunk against the whole signal's threshold
-    (SpectralGate.get_traces / _iterate_chunk); a shorter signal is the single chunk [0, n)."""
+def reduce_noise(y: np.ndarray, sr: int = 16000, prop_decrease: float = 1.0, n_std: float = 1.5,
+                 clip_noise_stationary: bool = True) -> np.ndarray:
+    """Any length: signals beyond CHUNK samples are filtered chunk by chunk (SpectralGate.get_traces / _iterate_chunk) against ONE
+    threshold; a shorter signal is the single chunk [0, n).  The threshold comes from the noise clip = the signal itself
+    (y_noise=None), which SpectralGateStationary.__init__ cuts to its first chunk_size samples when clip_noise_stationary is True
+    (the package default) [UPSTREAM-RECALL; parity unpinned -- False takes the whole signal]."""
     y = np.asarray(y, dtype=np.float32).reshape(-1)
     n = y.shape[0]
-    thresh = _thresholds(y, n_std)
+    thresh = _thresholds(y[:CHUNK] if clip_noise_stationary else y, n_std)
     out = np.zeros(n, dtype=np.float32)
     for start in range(0, n, CHUNK):
         end = min(start + CHUNK, n)

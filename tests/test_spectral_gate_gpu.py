@@ -48,18 +48,23 @@ def test_batch_equals_single_and_pads_zero(ccx_ctx):
         g.close()
 
 
+@pytest.mark.parametrize("clip_noise", [True, False])
 @pytest.mark.parametrize("seconds", [35.0, 45.0, 80.3])
-def test_long_signal_chunked_path_matches_oracle(ccx_ctx, seconds):
+def test_long_signal_chunked_path_matches_oracle(ccx_ctx, seconds, clip_noise):
     """Signals beyond the batch capacity / noisereduce's 600000-sample chunk (reference: whole files go through nr.reduce_noise,
-    back/api.py:832): threshold from the whole signal, chunks with 30000 samples of real context.  35 s = one chunk through the
-    long entry, 45 s = two chunks, 80.3 s = three (the last one short)."""
+    back/api.py:832): one threshold -- from the first 600000 samples (clip_noise_stationary=True, the package default as recalled) or
+    from the whole signal (False; parity unpinned, hence one switch on both sides) --, chunks with 30000 samples of real context.
+    35 s = one chunk through the long entry, 45 s = two chunks, 80.3 s = three (the last one short)."""
     from clearconverse_amd.denoise import SpectralGate
-    g = SpectralGate(max_samples=480000, max_clips=4, ctx=ccx_ctx)
+    g = SpectralGate(max_samples=480000, max_clips=4, ctx=ccx_ctx, clip_noise_stationary=clip_noise)
     try:
         n = int(seconds * 16000)
         x = np.concatenate([synthetic_clip(20 + i, 30.0) * (1.0 if i % 2 == 0 else 0.4) for i in range(3)])[:n]
         got = g(x, 16000, 0.5)
-        ref = reduce_noise(x, 16000, 0.5)
+        ref = reduce_noise(x, 16000, 0.5, clip_noise_stationary=clip_noise)
+        if n > 600000:      # the switch matters: the other setting gives another signal
+            other = reduce_noise(x, 16000, 0.5, clip_noise_stationary=not clip_noise)
+            assert _rel(other, ref) > 1e-4
         assert got.shape == ref.shape
         within("spectral gate (chunked, > 37.5 s): denoised signal rel-L2", _rel(got, ref), 1e-5)
         for seam in range(600000, n, 600000):              # no discontinuity at a chunk seam
