@@ -182,3 +182,16 @@ def test_pyannote_loader_fails_loudly_on_wrong_architecture_and_reports_refused_
         (_hub(tmp_path, "speaker-diarization", "pyannote/speaker-diarization-3.1") / "config.yaml").write_text(
             "params:\n  clustering:\n    method: average\n    min_cluster_size: 12\n    threshold: 0.7\n")
         W.find_pipeline_config("diarization")
+
+
+def test_conform_accepts_size_one_dimensions_only(tmp_path, monkeypatch):
+    """a checkpoint tensor whose shape differs from the architecture's may be reshaped only when nothing but size-1
+    dimensions differ (element order unchanged); a transposed / permuted weight of the same numel is an error, not a silent reshape."""
+    from clearconverse_amd import weights as W
+    schema = {"a": torch.zeros(4, 6), "b": torch.zeros(5), "c": torch.zeros(3, 1, 7)}
+    ok = W._conform("x", {"a": torch.arange(24.).reshape(4, 6, 1), "b": torch.arange(5.).reshape(1, 5), "c": torch.arange(21.).reshape(3, 7)}, schema, "f")
+    assert ok["a"].shape == (4, 6) and ok["b"].shape == (5,) and ok["c"].shape == (3, 1, 7) and torch.equal(ok["a"].flatten(), torch.arange(24.))
+    with pytest.raises(ValueError, match="has shape"):
+        W._conform("x", {"a": torch.zeros(6, 4), "b": torch.zeros(5), "c": torch.zeros(3, 1, 7)}, schema, "f")      # transposed
+    with pytest.raises(ValueError, match="lacks"):
+        W._conform("x", {"a": torch.zeros(4, 6)}, schema, "f")
