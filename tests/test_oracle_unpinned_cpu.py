@@ -24,13 +24,17 @@ def test_spectral_gate_knob_limits():
 
 
 def test_spectral_gate_multi_chunk_equals_single_chunk_away_from_the_seams(monkeypatch):
-    """The chunked path (threshold from the whole signal, chunks with real-neighbour padding): with a small chunk size the result
-    must equal the one-chunk result except near chunk seams, where each chunk's own dB floor / mask smoothing ends."""
+    """The chunked path (ONE threshold, chunks with real-neighbour padding): with a small chunk size and the threshold taken from the
+    whole signal (clip_noise_stationary=False) the result must equal the one-chunk result except near chunk seams, where each chunk's
+    own dB floor / mask smoothing ends.  With the noise clip cut to the first chunk (the default) the threshold -- and the result --
+    differ, which is what the switch is for."""
     x = synthetic_clip(3, 6.0)
     one = G.reduce_noise(x, 16000, prop_decrease=0.8)
     monkeypatch.setattr(G, "CHUNK", 40000)
     monkeypatch.setattr(G, "PADDING", 4000)
-    many = G.reduce_noise(x, 16000, prop_decrease=0.8)
+    many = G.reduce_noise(x, 16000, prop_decrease=0.8, clip_noise_stationary=False)
+    clipped = G.reduce_noise(x, 16000, prop_decrease=0.8, clip_noise_stationary=True)
+    assert float(np.linalg.norm(clipped - many) / np.linalg.norm(many)) > 1e-4
     assert many.shape == one.shape
     rel = float(np.linalg.norm(many - one) / np.linalg.norm(one))
     assert rel < 0.05, rel              # same threshold; only the per-chunk dB floor (max - 80) can differ
