@@ -520,6 +520,10 @@ def main():
                 gbs = float(np.mean([l["gbs"] for l in in_situ]))
                 roof["achieved_in_situ"] = round(gbs, 1)
                 roof["frac_in_situ"] = round(gbs / PEAK_HBM_GBS, 4)
+                # time per pipeline step of this kernel at the in-situ launch time: launches per step x median lane launch (the per-grid
+                # rocprofv3 summary of the same command times the same launches, with the lanes serialised by the tracer)
+                launches_step = pagg[name][0] / probe_steps * decode_steps_per_step
+                roof["ms_per_step_in_situ"] = round(float(np.mean([l["median_us"] for l in in_situ])) * launches_step * 1e-3, 2)
                 steps = [l["step_median_us"] for l in in_situ if l.get("step_median_us")]
                 if steps:
                     # the WHOLE decode step of the group: every lane's cross-KV + the decoder weights each lane streams once per step
