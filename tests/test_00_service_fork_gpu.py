@@ -7,11 +7,10 @@ created on first use: DESIGN.md section 1).
 The test IS that: the parent imports torch and clearconverse_amd without initialising HIP, forks, and the child runs
 `service.run_transcription_process` on a WAV with libccx-backed models.  This file sorts first so that, in the driver's single pytest
 process, it runs before any other test has created a GPU context (nothing initialises HIP at collection time); if HIP is already up
-in this process (another order, -k selections), the same parent is started as a fresh interpreter instead."""
+in this process (another order, -k selections) the test skips: run the file on its own."""
 import json
 import multiprocessing as mp
 import os
-import subprocess
 import sys
 from pathlib import Path
 
@@ -85,12 +84,9 @@ def _check(r: dict) -> None:
 
 
 def test_forked_child_of_a_gpu_free_parent_runs_the_task_protocol(tmp_path):
-    if not torch.cuda.is_initialized():
-        r = _parent(str(tmp_path))                                       # this pytest process is the GPU-free server
-    else:
-        code = ("import json, sys; sys.path.insert(0, sys.argv[1]); from tests.test_00_service_fork_gpu import _parent; "
-                "print('RESULT ' + json.dumps(_parent(sys.argv[2])))")
-        cp = subprocess.run([sys.executable, "-c", code, str(ROOT), str(tmp_path)], capture_output=True, text=True, timeout=900)
-        assert cp.returncode == 0, cp.stderr[-3000:]
-        r = json.loads([l for l in cp.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    _check(r)
+    if torch.cuda.is_initialized():
+        # another order / selection initialised HIP in this process first: forking now would hand the child a broken runtime, and
+        # starting a fresh interpreter from a GPU-initialised process is exactly the exec the GPU box forbids.  In the driver's
+        # `pytest tests -m gpu` this file runs first and the branch is never taken.
+        pytest.skip("HIP is already initialised in this process; run this file first (python -m pytest tests/test_00_service_fork_gpu.py -m gpu)")
+    _check(_parent(str(tmp_path)))                                       # this pytest process is the GPU-free server
