@@ -36,6 +36,18 @@
 #ifndef CCX_ABL_NO_EPI
 #define CCX_ABL_NO_EPI 0
 #endif
+// Experiment switches of the tile epilogue (compile time; tools/README.md): non-temporal stores of the output tile (CCX_EPI_NT_STORE) and
+// non-temporal loads of the residual rows (CCX_EPI_NT_LOAD) -- every output / residual byte of these launches is touched once.
+#ifndef CCX_EPI_NT_STORE
+#define CCX_EPI_NT_STORE 0
+#endif
+#ifndef CCX_EPI_NT_LOAD
+#define CCX_EPI_NT_LOAD 0
+#endif
+// fp32-residual epilogue of FULL 256 x 256 tiles through the LDS (see resid_via_lds below); 0 = the register-staged groups
+#ifndef CCX_EPI_RESID_LDS
+#define CCX_EPI_RESID_LDS 1
+#endif
 #ifndef CCX_ABL_STORE_LOCAL
 #define CCX_ABL_STORE_LOCAL 0
 #endif
@@ -60,6 +72,20 @@ template <int CM> __device__ __forceinline__ int keyW(int r) {
 template <int CM> __device__ __forceinline__ int col4(int j, int h) {
   return CM == 1 ? 16 * j + 4 * h : 32 * (j >> 1) + 8 * h + 4 * (j & 1);
 }
+typedef unsigned int ccx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epi_store16(void* dst, uint4 v) {
+  if (CCX_EPI_NT_STORE) __builtin_nontemporal_store((ccx_u32x4){v.x, v.y, v.z, v.w}, (ccx_u32x4*)dst);
+  else *(uint4*)dst = v;
+}
+__device__ __forceinline__ void epi_store16f(void* dst, float4 v) {
+  if (CCX_EPI_NT_STORE) __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, (f32x4*)dst);
+  else *(float4*)dst = v;
+}
+__device__ __forceinline__ float4 epi_load16f(const float* src) {
+  if (CCX_EPI_NT_LOAD) { const f32x4 t = __builtin_nontemporal_load((const f32x4*)src); return make_float4(t[0], t[1], t[2], t[3]); }
+  return *(const float4*)src;
+}
+
 constexpr int colmap_of(int epi) { return (epi == EPI_F32 || epi == EPI_F32_RESID || epi == EPI_F32_GELU_POS) ? 1 : 2; }
 
 // Block geometry: WM x WN waves, each wave owns (MT*16) x 64 outputs as MT x 4 accumulators.
@@ -280,7 +306,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const int cj = (FULL || c4[j] < Nw) ? c4[j] : 0;
-            if (have) G.rf[g][j] = *(const float4*)(p.resid + rrow * p.ldr + cj);
+            if (have) G.rf[g][j] = epi_load16f(p.resid + rrow * p.ldr + cj);
             else G.rf[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
@@ -331,7 +357,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
             uint4 o;
             o.x = pack_bf16x2(v[8 * i], v[8 * i + 1]);     o.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
             o.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); o.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
-            *(uint4*)(dst + (c4[2 * i] - cb)) = o;
+            epi_store16(dst + (c4[2 * i] - cb), o);
           }
           continue;
         }
@@ -381,7 +407,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
             uint4 o;
             o.x = pack_bf16x2(v[8 * i], v[8 * i + 1]);     o.y = pack_bf16x2(v[8 * i + 2], v[8 * i + 3]);
             o.z = pack_bf16x2(v[8 * i + 4], v[8 * i + 5]); o.w = pack_bf16x2(v[8 * i + 6], v[8 * i + 7]);
-            *(uint4*)(dst + c4[2 * i]) = o;
+            epi_store16(dst + c4[2 * i], o);
           }
         } else {
           if (EPI == EPI_F32_GELU_POS) {
@@ -398,7 +424,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (!FULL && c4[j] >= Nw) continue;
-            *(float4*)(dst + c4[j]) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            epi_store16f(dst + c4[j], make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
           }
         }
       }
@@ -419,6 +445,74 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     return;
   }
   const bool full = p.rpb_in <= 0 && m0 + WM * MT * 16 <= p.M && n0 + WN * 64 <= p.N;
+  if constexpr (CCX_EPI_RESID_LDS && EPI == EPI_F32_RESID && WM * WN == 8 && MT == 8) {
+    // fp32 residual of a FULL 256 x 256 tile THROUGH THE LDS (round 3).  The register-staged path above keeps two row tiles of
+    // residual (8 float4) in flight per lane = 64 KB per CU and needs four dependent HBM round trips per tile, each ~2.5 us under
+    // load: 512 KB of read-modify-write at ~22 GB/s per CU, latency-bound (Little), not bandwidth-bound.  The operand image is dead
+    // once the main loop is over, so the residual rows travel by LDS-DMA instead -- no registers while in flight: a wave fetches the
+    // 64 rows x 64 columns (16 KB, 16 DMA instructions of 4 rows x 256 B) of one HALF of its 128 x 64 block into its own 16 KB of
+    // LDS, 128 KB in flight per CU, two round trips, and the second half is requested before the first half's sums are stored.
+    // Image: row r = 256 B = 16 chunks of 16 B; chunk c of the LDS row holds global chunk c ^ (r & 15) (swizzle on the DMA source),
+    // the lane of row l15 that wants chunk 4 j + h reads (4 j + h) ^ l15: conflict-free for ds_read_b128.  Same arithmetic, same
+    // order ((acc + bias) + residual): bit-identical to the register path.
+    if (full && p.resid != nullptr && p.resid_mod == 0) {
+      __syncthreads();                       // every wave is done with the operand image (all DMA was waited for in the last phase)
+      char* my = smem + wave * 16384;
+      const float* rbase = p.resid + (long)(m0 + wr * MT * 16) * p.ldr + cb;
+      auto fetch_half = [&](int hh) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int rl = 4 * i + (lane >> 4);                 // row inside the half (0..63)
+          const int ch = (lane & 15) ^ (rl & 15);             // global chunk that lands in LDS chunk (lane & 15)
+          __builtin_amdgcn_global_load_lds((gptr_t)(rbase + (long)(hh * 64 + rl) * p.ldr + 4 * ch), (lptr_t)(my + i * 1024), 16, 0, 0);
+        }
+      };
+      // two row tiles (32 rows) at a time: 8 ds_read_b128 -> 32 registers of residual -> 8 stores
+      auto read_pair = [&](int qq, float4 (&rf)[2][4]) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            f32x4 t;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"((unsigned)(uintptr_t)(lptr_t)(my + ((2 * qq + q) * 16 + l15) * 256 + (((4 * j + h) ^ l15) << 4))));
+            rf[q][j] = make_float4(t[0], t[1], t[2], t[3]);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto finish_pair = [&](int hh, int qq, const float4 (&rf)[2][4]) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int mt = hh * 4 + 2 * qq + q;
+          const long orow = m0 + wr * MT * 16 + mt * 16 + l15;
+          float* dst = (float*)p.out + orow * p.ldo;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float4 o;
+            o.x = (acc[mt][j][0] + bias[4 * j + 0]) + rf[q][j].x; o.y = (acc[mt][j][1] + bias[4 * j + 1]) + rf[q][j].y;
+            o.z = (acc[mt][j][2] + bias[4 * j + 2]) + rf[q][j].z; o.w = (acc[mt][j][3] + bias[4 * j + 3]) + rf[q][j].w;
+            epi_store16f(dst + c4[j], o);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      float4 rf[2][4];
+      fetch_half(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's own 16 DMA instructions (nobody else reads this region)
+      read_pair(0, rf);
+      finish_pair(0, 0, rf);                                 // 8 stores
+      read_pair(1, rf);                                      // every read of half 0 has completed (lgkmcnt(0)) ...
+      fetch_half(1);                                         // ... so its region may be overwritten
+      __builtin_amdgcn_sched_barrier(0);                     // the vmcnt(8) below counts on this issue order: 8 stores, 16 DMA, 8 stores
+      finish_pair(0, 1, rf);                                 // 8 stores behind the DMA
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // in-order retirement: the DMA (and the 8 older stores) are done
+      read_pair(0, rf);
+      finish_pair(1, 0, rf);
+      read_pair(1, rf);
+      finish_pair(1, 1, rf);
+      return;
+    }
+  }
   if (full) rows(std::true_type{});
   else rows(std::false_type{});
 }
