@@ -85,12 +85,17 @@ def test_pmc_reduction_doubles_fetch_and_reads_sequences_off_the_grid(tmp_path):
                 w.writerow([d, name, grid, counter, val])
     name = "void dec_cross_stream_kernel<true, 12, false>(DecAttnParams)"
     # two dispatches, counter split over 8 XCD rows each (rocprofv3 prints one row per instance)
-    write(tmp_path / "f.csv", "FETCH_SIZE", [(d, name, 384 * 12 * 256, 864000.0 / 8) for d in (1, 2) for _ in range(8)])
-    write(tmp_path / "w.csv", "WRITE_SIZE", [(d, name, 384 * 12 * 256, 576.0 / 8) for d in (1, 2) for _ in range(8)])
+    # ... plus ONE launch of another shape (bench.py's probe decodes a smaller group): it must not be averaged into the main entry
+    write(tmp_path / "f.csv", "FETCH_SIZE", [(d, name, 384 * 12 * 256, 864000.0 / 8) for d in (1, 2) for _ in range(8)]
+          + [(3, name, 336 * 12 * 256, 756000.0 / 8) for _ in range(8)])
+    write(tmp_path / "w.csv", "WRITE_SIZE", [(d, name, 384 * 12 * 256, 576.0 / 8) for d in (1, 2) for _ in range(8)]
+          + [(3, name, 336 * 12 * 256, 504.0 / 8) for _ in range(8)])
     out = tmp_path / "pmc.json"
     subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_to_json.py"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), str(out), "test note"],
                    check=True, capture_output=True)
-    d = json.loads(out.read_text())["dec_cross_stream_kernel<true,12,false>"]
-    assert d["launches"] == 2 and d["sequences_per_launch"] == 384
+    all_ = json.loads(out.read_text())
+    d = all_["dec_cross_stream_kernel<true,12,false>"]
+    assert d["launches"] == 2 and d["sequences_per_launch"] == 384 and d["sequences_per_launch_seen"] == [336, 384]
+    assert all_["dec_cross_stream_kernel<true,12,false> @336"]["hbm_bytes_per_launch"] == pytest.approx((2 * 756000.0 + 504.0) * 1024.0)
     assert d["hbm_bytes_per_launch"] == pytest.approx((2 * 864000.0 + 576.0) * 1024.0)        # FETCH_SIZE counts half of a wide read on gfx950
     assert d["note"].startswith("test note")

@@ -12,12 +12,14 @@ tag=${1:-r03}
 steps=${2:-4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
+if [ "${3:-pmc}" != "pmconly" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o ks -- python3 bench.py --steps $steps --warmup 4 --no-cpu-baseline --no-comparisons > gpurun_out/${tag}_bench_under_rocprof.log 2>&1 || exit 1
 cp "$(find /tmp/prof_ks -name 'ks_kernel_stats.csv' | head -1)" gpurun_out/${tag}_default_kernel_stats.csv || exit 1
 python3 tools/kernel_trace_by_grid.py "$(find /tmp/prof_ks -name 'ks_kernel_trace.csv' | head -1)" gpurun_out/${tag}_default_kernel_stats_by_grid.csv || exit 1
 grep '^{"metric"' gpurun_out/${tag}_bench_under_rocprof.log > gpurun_out/${tag}_bench_under_rocprof.json
 rm -rf /tmp/prof_ks
-if [ "${3:-pmc}" = "pmc" ]; then
+fi
+if [ "${3:-pmc}" != "nopmc" ]; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o f -- python3 bench.py --workload whisper --batch 384 --steps 1 --warmup 0 --sample-len 4 --no-cpu-baseline > /tmp/pmc_f.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o w -- python3 bench.py --workload whisper --batch 384 --steps 1 --warmup 0 --sample-len 4 --no-cpu-baseline > /tmp/pmc_w.log 2>&1 || exit 1
 python3 tools/pmc_to_json.py "$(find /tmp/prof_f -name 'f_counter_collection.csv' | head -1)" "$(find /tmp/prof_w -name 'w_counter_collection.csv' | head -1)" gpurun_out/${tag}_pmc_traffic.json \

@@ -17,11 +17,15 @@ def load(path, counter):
             for pre in ("void ", "(anonymous namespace)::"):
                 name = name.replace(pre, "")
             name = name.split("(")[0].replace(", ", ",")      # "dec_cross_stream_kernel<true,12,false>": the label bench.py uses
+            g = r.get("Grid_Size") or r.get("Grid_Size_X")
+            if name.startswith("dec_cross_stream_kernel") and g:
+                # one entry per launch shape (bench.py's probe decodes a slightly smaller group than the timed region): the shape with
+                # the most launches becomes the kernel's entry below, the others stay beside it as "<name> @<sequences>"
+                name = f"{name} @{int(g) // 256 // 12}"
             key = (r["Dispatch_Id"], name)
             a = per[name]
             if key not in seen:
                 seen.add(key); a[0] += 1
-                g = r.get("Grid_Size") or r.get("Grid_Size_X")
                 if g:
                     GRID.setdefault(name, set()).add(int(g))
             a[1] += float(r["Counter_Value"])
@@ -57,11 +61,15 @@ for name, (n, fk, wk) in base.items():
                      "hbm_bytes_per_launch": (2.0 * fk + wk) / n * 1024.0, "note": note + "; all template instantiations together"}
 # Counter collection serialises dispatches, so the decode-lane stream probe finds no concurrent stream and a decode group runs in
 # ONE lane: the sequences a cross-attention launch covers are read off its grid (one 256-thread block per (sequence, head), 12 heads).
+shapes = collections.defaultdict(list)
 for name in list(out):
-    if name.startswith("dec_cross_stream_kernel") and "false>" in name and GRID.get(name):
-        seqs = sorted(g // 256 // 12 for g in GRID[name])
-        out[name]["sequences_per_launch"] = seqs[-1] if len(seqs) == 1 else None
-        out[name]["sequences_per_launch_seen"] = seqs
+    if name.startswith("dec_cross_stream_kernel") and " @" in name:
+        base_name, seqs = name.split(" @")
+        out[name]["sequences_per_launch"] = int(seqs)
+        shapes[base_name].append((out[name]["launches"], int(seqs), name))
+for base_name, lst in shapes.items():
+    lst.sort(reverse=True)
+    out[base_name] = dict(out[lst[0][2]], sequences_per_launch_seen=sorted(sq for _, sq, _ in lst))
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
 for k, v in top:
