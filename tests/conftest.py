@@ -11,6 +11,11 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracles are chains of small torch ops (a 589-step LSTM loop, 3 x 3 convolutions on short chunks): on the GPU box's
+    # 256 host cores torch's default thread count makes them several times SLOWER than on 8-16 threads (the two pipeline parity
+    # tests took 160 s and 90 s).  Importing torch does not touch the GPU.
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
