@@ -65,6 +65,22 @@ def test_ten_second_chunk_and_geometry_change(net):
     assert _rel(got2[0], R.resnet_embed(sd, short)[0]) < TOL
 
 
+def test_results_do_not_depend_on_the_geometry_history(net, ccx_ctx):
+    """Only the halo cells of the chunks in use are re-zeroed when the frame count changes or more chunks come into use
+    (halo_zero_kernel): long -> short -> long with MORE chunks -> shorter with fewer must each be bit-identical to a fresh instance."""
+    from clearconverse_amd.speaker import ResNetEmbedder
+    sd, emb = net
+    calls = [(160000, 2), (24000, 5), (160000, 6), (8000, 1), (24000, 8), (159000, 8), (160000, 1)]
+    for k, (n, chunks) in enumerate(calls):
+        waves = torch.from_numpy(np.stack([_clip(60 + k * 8 + i, n, 100 * i) for i in range(chunks)]))
+        got = emb.embed_chunks(waves).cpu()
+        fresh = ResNetEmbedder(sd, max_chunks=8, max_samples=160000, max_masks=32, ctx=ccx_ctx)
+        want = fresh.embed_chunks(waves).cpu()
+        assert torch.isfinite(got).all()
+        assert torch.equal(got, want), (k, n, chunks)
+        del fresh
+
+
 def test_chunk_results_do_not_depend_on_batch_mates(net):
     """Size-independent property at the pipeline's chunk size (10 s): an embedding is bit-identical whatever else is in
     the launch (GEMM tiles straddle chunk boundaries, but every output element sees only its own chunk)."""
