@@ -38,20 +38,29 @@ MFMA_KERNELS = ("gemm_bf16_nt_kernel", "enc_attention_kernel")
 
 
 def enc_flops_per_window(d):
-    """SURVEY.md section 8d formula (encoder incl. conv stem) + cross-KV projection."""
+    """SURVEY.md section 8d formula (encoder incl. conv stem); the second figure is the cross-K/V projection of the 12 decoder layers,
+    which round 3's decode no longer computes for groups of more than 16 sequences (the cross attention reads the encoder output
+    itself, csrc/cross_x.hip) -- reported, not counted."""
     D, L, S = d.n_audio_state, d.n_audio_layer, d.n_audio_ctx
     enc = 2 * (3000 * D * 3 * d.n_mels + S * D * 3 * D + L * (S * (4 * D * D + 2 * D * 4 * D) + 2 * S * S * D))
     cross = 2 * d.n_text_layer * 2 * S * D * D
     return enc, cross
 
 
-def decode_bytes_per_step(d, B):
-    """Algorithmic HBM bytes of one decode step: bf16 decoder weights + tied embedding once, plus each
-    sequence's cross-attention K/V."""
+def cross_bytes_per_sequence(d, xstream=True):
+    """Algorithmic HBM bytes of ONE layer's cross attention for ONE sequence and decode step.  The reference's formulation reads the
+    layer's K and V (2 x n_audio_ctx x D bf16); the X-stream formulation reads the encoder output once
+    (n_audio_ctx x D bf16) plus the expanded queries in and the contexts out (2 x heads x D bf16)."""
+    D, S, H = d.n_text_state, d.n_audio_ctx, d.n_text_head
+    return S * D * 2 + 2 * H * D * 2 if xstream else 2 * S * D * 2
+
+
+def decode_bytes_per_step(d, B, xstream=True):
+    """Algorithmic HBM bytes of one decode step: bf16 decoder weights + tied embedding once, plus each sequence's cross attention
+    (see cross_bytes_per_sequence)."""
     D, L = d.n_text_state, d.n_text_layer
-    w = 2 * (L * (4 * D * D + 2 * D * 4 * D + 4 * D * D) + d.n_vocab * D)   # self (qkv+o) + mlp + cross (q,o + k,v not re-read) + logits
-    kv = B * L * 2 * d.n_audio_ctx * D * 2
-    return w + kv
+    w = 2 * (L * (4 * D * D + 2 * D * 4 * D + 4 * D * D) + d.n_vocab * D)   # self (qkv+o) + mlp + cross (q, k, v, o) + logits
+    return w + B * L * cross_bytes_per_sequence(d, xstream)
 
 
 def cpu_baseline_whisper(dims, sd, clip, rules, threads, tokens):
@@ -392,6 +401,8 @@ def main():
     if pipeline and args.stage_times:
         bp.stage_ms = {}
         bp.run_pinned(audio, timed=True)
+    # which cross attention the decode groups run (CCX_CROSS_X=0 at model creation: round 2's per-layer K/V caches)
+    xstream = os.environ.get("CCX_CROSS_X", "1") != "0" and dims.n_text_state in (128, 256, 384, 512, 768) and dims.n_text_head * 64 == dims.n_text_state
     # ---- decode probe: the decode chain runs inside hipGraphs in the timed region, where single launches
     # cannot be bracketed by events.  Re-run a few decode steps of the SAME batch eagerly (CCX_NO_GRAPH) with the
     # per-launch HIP events on, to get the average launch duration of the graph-resident kernels.
@@ -427,7 +438,7 @@ def main():
         torch.cuda.synchronize()
         wm.trace_lanes(None)
         if os.path.exists(tr):
-            in_situ = lane_cross_attention_in_situ(tr, dims.n_text_head * dims.n_audio_ctx * (dims.n_text_state // dims.n_text_head) * 2 * 2)
+            in_situ = lane_cross_attention_in_situ(tr, cross_bytes_per_sequence(dims, xstream))
             os.remove(tr)
     # decode launches per pipeline step: a unit of `span` batches is decoded in ceil(6 B span / Bd) groups
     decode_steps_per_step = (args.sample_len + 1) * (((6 * B * span + Bd - 1) // Bd) / span if pipeline else 1)
@@ -470,7 +481,7 @@ def main():
             if traffic is not None and pmc.get("sequences_per_launch"):
                 # measured at `sequences_per_launch` per launch (counter passes serialise the lanes); equal to this run's launch
                 # shape when the newest committed pass was taken at it, scaled by the sequence count otherwise
-                traffic = traffic / pmc["sequences_per_launch"] * (by / cnt_) / (dims.n_audio_ctx * dims.n_text_state * 2 * 2)
+                traffic = traffic / pmc["sequences_per_launch"] * (by / cnt_) / cross_bytes_per_sequence(dims, xstream)
             return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic,
                         traffic_source=(f"{pfs[-1].name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {pmc.get('sequences_per_launch')} sequences per launch there"
@@ -514,7 +525,7 @@ def main():
             cnt_, fl, by, ms = src[name]
             roof = roof_entry(name, cnt_, fl, by, ms, per_step[name][1])
             roof["ms_per_step"] = round(per_step[name][0], 2)
-            if name.startswith("dec_cross_stream_kernel") and in_situ:
+            if name.startswith(("dec_cross_stream_kernel", "dec_xs_stream_kernel")) and in_situ:
                 # the same kernel inside the replayed step graphs with every lane of the group running: bytes of a lane's launch /
                 # median stamp-to-stamp time, averaged over the lanes
                 gbs = float(np.mean([l["gbs"] for l in in_situ]))
@@ -528,7 +539,7 @@ def main():
                 if steps:
                     # the WHOLE decode step of the group: every lane's cross-KV + the decoder weights each lane streams once per step
                     # (self-KV is < 1 % at the trace's <= 24 positions), all lanes concurrent, over the median lane step time
-                    by_step = float(sum(decode_bytes_per_step(dims, l["sequences"]) for l in in_situ))
+                    by_step = float(sum(decode_bytes_per_step(dims, l["sequences"], xstream) for l in in_situ))
                     roof["decode_step_in_situ"] = dict(bytes=by_step, median_us=round(float(np.mean(steps)), 1),
                                                        achieved=round(by_step / (float(np.mean(steps)) * 1e-6) / 1e9, 1),
                                                        frac=round(by_step / (float(np.mean(steps)) * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), unit="GB/s",
@@ -546,17 +557,18 @@ def main():
                 roof_mfma["whisper_encoder_gemms"] = dict(achieved=round(ach, 2), unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4),
                                                           launches=enc_n, ms_per_step=round(enc_ms / prof_steps, 2))
                 # the WHOLE encoder: its GEMMs + attention + LayerNorms (every launch between log-mel and the decoder) against the
-                # algorithmic 386.7 GFLOP per window (encoder 344.2 + cross-KV projection 42.5)
+                # algorithmic GFLOP per window (encoder 344.2; + cross-KV projection 42.5 only where it is still computed)
                 att_ms = sum(ms for n_, _, _, ms in recs if n_ == "enc_attention_kernel")
                 ln_ms = sum(ms for n_, _, _, ms in recs0 if n_.startswith("layernorm_kernel M=") and f" M={nwin * dims.n_audio_ctx} " in n_ + " ")
                 wins = (6 * B if pipeline else B) * prof_steps
                 tot_ms = enc_ms + att_ms + ln_ms
-                fl_tot = wins * float(sum(enc_flops_per_window(dims)))
+                gfl_win = float(enc_flops_per_window(dims)[0] + (0 if xstream else enc_flops_per_window(dims)[1]))
+                fl_tot = wins * gfl_win
                 ach_t = fl_tot / (tot_ms * 1e-3) / 1e12
                 roof_mfma["whisper_encoder_total"] = dict(achieved=round(ach_t, 2), unit="TFLOP/s", frac=round(ach_t / PEAK_MFMA_BF16_TFLOPS, 4),
                                                           gemm_ms=round(enc_ms / prof_steps, 2), attention_ms=round(att_ms / prof_steps, 2),
                                                           layernorm_ms=round(ln_ms / prof_steps, 2), windows_per_step=wins // prof_steps,
-                                                          gflop_per_window=round(sum(enc_flops_per_window(dims)) / 1e9, 1))
+                                                          gflop_per_window=round(gfl_win / 1e9, 1))
         stage_ms = {k: round(v[3] / prof_steps, 3) for k, v in agg.items()}
         stage_ms.update({k: round(v[0], 3) for k, v in per_step.items()})
 
@@ -592,7 +604,9 @@ def main():
                else "whisper_small_en_logmel_encode_greedy_decode (BASELINE configs[1])",
                "clips_per_gpu": B, "clip_seconds": 30, "sample_len": args.sample_len, "whisper_calls": n_calls,
                "tokens_decoded": n_tokens, "parallelism": f"clip-sharded x{world}",
-               "encoder_gflop_per_window": round((enc_f + cross_f) / 1e9, 1)}
+               "encoder_gflop_per_window": round((enc_f + (0 if xstream else cross_f)) / 1e9, 1),
+               "cross_attention": ("against the encoder output: one pass over xa per layer and sequence serves all heads, no K/V caches "
+                                   "(csrc/cross_x.hip; decodes of <= 16 sequences keep per-layer K/V)" if xstream else "per-layer K/V caches (CCX_CROSS_X=0)")}
         if pipeline:
             cfg["schedule"] = ("pinned synthetic schedule (SURVEY.md 8d): per clip 2 regular + 2 overlap-bearing segments -> "
                                "6 Whisper windows, 4 separator regions, 62 x-vector crops; VAD (51 x 5 s chunks) and diarization "

@@ -1,0 +1,31 @@
+// cross_x.h -- decode cross attention against the ENCODER OUTPUT (cross_x.hip).
+#pragma once
+#include "ccx_common.h"
+
+// Whisper's decoder cross attention (openai-whisper model.py MultiHeadAttention with xa; called once per layer and decode step from
+// back/api.py:1286-1292 / 1432-1438 / 1474-1480 through transcribe()) reads, per layer, K = xa Wk^T and V = xa Wv^T + bv of every
+// sequence: 2 x 1500 x 768 bf16 per layer and sequence, 12 different caches for the 12 layers -- 94 % of a decode step's HBM bytes.
+// Both are linear images of the SAME xa, so
+//     scores_h[j] = q_h . K_j,h           = (q_h Wk_h) . xa_j            -- "expanded query" q'_h = q_h Wk_h, one 768-vector per head
+//     out_h       = sum_j p_hj V_j,h      = (sum_j p_hj xa_j) Wv_h^T + bv -- (sum_j p_hj = 1)
+// and one pass over xa (1500 x 768 bf16, shared by all layers) serves all heads: half the bytes per layer, and 1/24 of the cache.
+// The price is 12 x the matrix work (every head against all 768 features instead of its 64), which goes to the matrix cores:
+// heads are the N index of the MFMAs.
+struct XsParams {
+  const float* q;        // [rows][D] f32 queries (bias included, not scaled)
+  const bf16_t* WkT;     // [H][D][64]: WkT[h][f][d] = Wk[h*64 + d][f]   (cross_attn.key.weight re-laid per head)
+  bf16_t* xq;            // [rows][H][D]: expanded queries (xq_expand) -> normalised contexts sum_j p_hj xa_j (xs_stream), in place
+  const bf16_t* X;       // [sequences][x_seq_stride]: encoder output rows [S][D] per sequence
+  long x_seq_stride;     // elements between sequences
+  const int* row_seq;    // row -> sequence (prompt prefill: several rows per sequence); null: identity
+  const bf16_t* Wv;      // [D][D] row-major cross_attn.value.weight
+  const float* bv;       // [D]
+  bf16_t* out;           // [rows][D] attention output (input of cross_attn.out)
+  int rows, H, S, D;
+  float scale_log2e;     // (d_head ^ -0.25)^2 * log2(e)
+};
+
+// the three launches of one layer's cross attention: q' = expand(q); ctx = softmax(q' xa^T) xa; out = ctx Wv^T + bv
+int ccx_launch_xs_cross_attention(ccx_ctx* ctx, const XsParams& p, hipStream_t stream);
+// widths the kernels are instantiated for
+bool ccx_xs_supported(int D, int H);

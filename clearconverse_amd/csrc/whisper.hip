@@ -13,6 +13,7 @@
 #include "../../include/ccx.h"
 #include "attention.h"
 #include "ccx_common.h"
+#include "cross_x.h"
 #include "decoder.h"
 #include "elementwise.h"
 #include "gemm_bf16.h"
@@ -58,6 +59,7 @@ struct DecLayer {
   float *ln1_g, *ln1_b, *lnc_g, *lnc_b, *ln2_g, *ln2_b;
   bf16_t *Wqkv, *Wo, *Wcq, *Wckv, *Wco, *W1, *W2;
   bf16_t* W1_plain = nullptr;   // fc1 once more in plain row-major [F][D] for the tiled GEMM (lanes of >= 256 rows, prefill)
+  bf16_t* WckT = nullptr;       // cross_attn.key.weight re-laid per head [H][D][64] for the expanded query (cross_x.hip)
   float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
   bf16_t *crossK, *crossV, *selfK, *selfV;
 };
@@ -132,6 +134,13 @@ struct ccx_whisper {
   int cross_lds_pad = 0;                     // see ccx_whisper_decode: occupancy cap of the cross-attention blocks while lanes overlap
   int cross_stream = 0;                      // 1: lean-streaming cross attention (dec_cross_stream_kernel) for batches > 16
   int fuse_cross_q = 1;                      // 1: batches <= 16 compute the cross-attention query inside the attention blocks
+  // Cross attention against the encoder output (cross_x.hip) for decodes of more than 16 sequences: no per-layer K/V caches at all
+  // (42 GB at 768 sequences), half the bytes per step.  xs_on: the instance was built for it (widths cross_x.hip instantiates,
+  // CCX_CROSS_X != 0 at finalize); the K/V caches then hold kv_cap = 16 sequences and are filled from xa at the start of a decode
+  // of <= 16 sequences (kv_ready = sequences valid since the last encode).
+  bool xs_on = false, xs_active = false;
+  int kv_cap = 0, kv_ready = 0;
+  bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries / contexts [rows][H][D] (step rows, prefill rows)
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
                                              // queue run strictly one after the other, so lanes are picked by a probe
@@ -495,6 +504,11 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   }
   w->dec.resize(d.n_text_layer);
   const int Tc = d.n_text_ctx;
+  {
+    const char* e = getenv("CCX_CROSS_X");      // 0: round 2's per-layer cross K/V caches for every sequence (A/B)
+    w->xs_on = (!e || atoi(e) != 0) && d.n_text_state == D && d.n_text_head == H && ccx_xs_supported(D, H);
+    w->kv_cap = w->xs_on ? (B < 16 ? B : 16) : B;
+  }
   for (int l = 0; l < d.n_text_layer; l++) {
     const std::string p = "decoder.blocks." + std::to_string(l) + ".";
     DecLayer& L = w->dec[l];
@@ -526,7 +540,14 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     TRY(up_f32(w, &L.ln1_g, l1g->data.data(), D)); TRY(up_f32(w, &L.ln1_b, l1b->data.data(), D));
     TRY(up_f32(w, &L.lnc_g, lcg->data.data(), D)); TRY(up_f32(w, &L.lnc_b, lcb->data.data(), D));
     TRY(up_f32(w, &L.ln2_g, l2g->data.data(), D)); TRY(up_f32(w, &L.ln2_b, l2b->data.data(), D));
-    const size_t ck = (size_t)B * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
+    if (w->xs_on) {
+      std::vector<float> wkt((size_t)D * D);
+      for (int hh = 0; hh < H; hh++)
+        for (int f = 0; f < D; f++)
+          for (int dd = 0; dd < 64; dd++) wkt[((size_t)hh * D + f) * 64 + dd] = ckw->data[(size_t)(hh * 64 + dd) * D + f];
+      TRY(up_bf16(w, &L.WckT, wkt.data(), wkt.size()));
+    }
+    const size_t ck = (size_t)w->kv_cap * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
     TRY(dev_alloc(w, &L.crossK, ck, true)); TRY(dev_alloc(w, &L.crossV, ck, true));
     TRY(dev_alloc(w, &L.selfK, sk, true)); TRY(dev_alloc(w, &L.selfV, sk, true));
   }
@@ -537,7 +558,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   // per instance), so two instances whose log-mel / encode calls are ordered on ONE stream may share them (32 GB at 768 windows)
   if (ccx_whisper* dn = w->scratch_donor) {
     w->lm_raw = dn->lm_raw; w->lm_max = dn->lm_max; w->lm_n = dn->lm_n; w->lm_seek = dn->lm_seek; w->lm_seg = dn->lm_seg;
-    w->im2col = dn->im2col; w->h1 = dn->h1; w->x = dn->x; w->xn = dn->xn; w->xa = dn->xa;
+    w->im2col = dn->im2col; w->h1 = dn->h1; w->x = dn->x; w->xn = dn->xn;
     w->qb = dn->qb; w->kb = dn->kb; w->vtb = dn->vtb; w->attn = dn->attn; w->ffn = dn->ffn;
   } else {
     TRY(dev_alloc(w, &w->lm_raw, (size_t)B * 80 * w->Fraw, true));
@@ -549,7 +570,6 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     TRY(dev_alloc(w, &w->h1, ((size_t)B * 3002 + 2) * D, true));
     TRY(dev_alloc(w, &w->x, (size_t)B * S * D, true));
     TRY(dev_alloc(w, &w->xn, (size_t)B * S * D, true));
-    TRY(dev_alloc(w, &w->xa, (size_t)B * S * D, true));
     TRY(dev_alloc(w, &w->qb, (size_t)B * H * w->Spad * 64, true));
     TRY(dev_alloc(w, &w->kb, (size_t)B * H * w->Spad * 64, true));
     TRY(dev_alloc(w, &w->vtb, (size_t)B * H * 64 * w->Spad, true));
@@ -557,6 +577,12 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     TRY(dev_alloc(w, &w->ffn, (size_t)B * S * F, true));
   }
 
+  // the encoder output stays with the instance: the decode streams it (cross_x.hip); + one key tile of slack
+  TRY(dev_alloc(w, &w->xa, ((size_t)B * S + 16) * D, true));
+  if (w->xs_on) {
+    TRY(dev_alloc(w, &w->xq, (size_t)B * H * D, true));
+    TRY(dev_alloc(w, &w->pf_xq, (size_t)B * ccx_whisper::kPrefillMax * H * D, true));
+  }
   TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dx2, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->pend, (size_t)4 * B * D, true));
@@ -678,6 +704,35 @@ int ccx_whisper_set_mel(ccx_whisper* w, const float* mel, int B, void* stream_) 
   return CCX_OK;
 }
 
+// cross-attention K/V of sequences [0, n) for every decoder layer out of xa (head-major, not transposed: decode streams rows)
+static int project_cross_kv(ccx_whisper* w, int n, hipStream_t stream) {
+  const ccx_whisper_dims& d = w->d;
+  const int D = d.n_audio_state, S = d.n_audio_ctx, H = d.n_audio_head;
+  CCX_REQUIRE(w->ctx, n <= w->kv_cap, "whisper: cross K/V caches hold %d sequences, %d asked for", w->kv_cap, n);
+  GemmParams p;
+  for (int l = 0; l < d.n_text_layer; l++) {
+    const DecLayer& L = w->dec[l];
+    memset(&p, 0, sizeof(p));
+    p.A = w->xa; p.lda = D; p.W = L.Wckv; p.ldw = D; p.M = n * S; p.N = 2 * D; p.K = D; p.bias = L.bckv;
+    p.hk = L.crossK; p.hv = L.crossV; p.d_model = D; p.n_head = H; p.S = S; p.Spad = w->Spad; p.v_transposed = 0;
+    p.first_block = 1;
+    TRY(ccx_launch_gemm(w->ctx, EPI_HEADS, p, stream));
+  }
+  w->kv_ready = n;
+  return CCX_OK;
+}
+// which cross attention a decode of B sequences uses, and the K/V it needs
+static int select_cross_path(ccx_whisper* w, int B, hipStream_t stream) {
+  // CCX_CROSS_X_MIN_ROWS (read per call: tests flip it): smallest decode that takes the X-stream path.  Default 17: up to 16 rows the
+  // chain is latency-bound launch by launch and the split-KV kernels with the fused query are faster.  Within one path a sequence's
+  // numbers do not depend on its batch mates; across the two paths they agree to rounding (tests/test_whisper_gpu.py).
+  const char* e = getenv("CCX_CROSS_X_MIN_ROWS");
+  const int min_rows = e ? atoi(e) : 17;
+  w->xs_active = w->xs_on && B >= min_rows;
+  if (w->xs_on && !w->xs_active && w->kv_ready < B) TRY(project_cross_kv(w, B, stream));
+  return CCX_OK;
+}
+
 int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
   if (!w) return CCX_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
@@ -722,16 +777,10 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
     TRY(ccx_launch_gemm(ctx, EPI_F32_RESID, p, stream));
   }
   TRY(ccx_launch_layernorm(ctx, w->x, D, w->lnp_g, w->lnp_b, w->xa, xa_out, D, M, D, 1e-5f, stream));
-  // cross-attention K/V for every decoder layer (head-major, not transposed: decode streams rows)
-  for (int l = 0; l < d.n_text_layer; l++) {
-    const DecLayer& L = w->dec[l];
-    memset(&p, 0, sizeof(p));
-    p.A = w->xa; p.lda = D; p.W = L.Wckv; p.ldw = D; p.M = M; p.N = 2 * D; p.K = D; p.bias = L.bckv;
-    p.hk = L.crossK; p.hv = L.crossV; p.d_model = D; p.n_head = H; p.S = S; p.Spad = w->Spad; p.v_transposed = 0;
-    p.first_block = 1;
-    TRY(ccx_launch_gemm(ctx, EPI_HEADS, p, stream));
-  }
   TRY(scratch_release(w, stream));
+  // cross-attention K/V: with the X-stream cross attention only decodes of <= 16 sequences use them and project them themselves
+  w->kv_ready = 0;
+  if (!w->xs_on) TRY(project_cross_kv(w, B, stream));
   return CCX_OK;
 }
 
@@ -940,7 +989,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   static const int ablate = [] { const char* e = getenv("CCX_ABLATE"); return !e ? 0 : (!strcmp(e, "cross") ? 1 : (!strcmp(e, "chain") ? 2 : 0)); }();
   for (int l = 0; l < d.n_text_layer; l++) {
     const DecLayer& L = w->dec[l];
-    if (ablate == 2 && B > 16) {
+    if (ablate == 2 && B > 16 && !w->xs_active) {
       DecAttnParams ap;
       memset(&ap, 0, sizeof(ap));
       ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
@@ -968,10 +1017,25 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     // cross attention.  Small batches (<= 16 rows, d_model 768: the reference's one-window-per-call pattern): the query projection
     // LN(x) Wcq^T runs INSIDE the cross-attention blocks (ccx_launch_dec_cross_fused_q: one launch fewer per layer on a chain that
     // is latency-bound launch by launch; q is bit-identical to the two-launch path).  CCX_FUSE_CROSS_Q=0 restores the two launches.
-    const bool fuse_q = w->fuse_cross_q && !pre && B <= 16 && D == 768 && ablate == 0;
+    const bool fuse_q = w->fuse_cross_q && !pre && B <= 16 && D == 768 && ablate == 0 && !w->xs_active;
     if (!fuse_q) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
+    if (w->xs_active) {
+      // decodes of more than 16 sequences: one pass over the encoder output serves all heads (cross_x.hip)
+      if (ablate != 1) {
+        XsParams xp;
+        memset(&xp, 0, sizeof(xp));
+        xp.q = dq; xp.WkT = L.WckT; xp.xq = pre ? w->pf_xq : w->xq + ro * H * D;
+        xp.X = pre ? w->xa : w->xa + ro * (long)d.n_audio_ctx * D; xp.x_seq_stride = (long)d.n_audio_ctx * D; xp.row_seq = row_seq;
+        xp.Wv = L.Wckv + (long)D * D; xp.bv = L.bckv + D; xp.out = dattn;
+        xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
+        TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
+      }
+      stamp(2, 1);
+      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+      stamp(19, 2);
+    } else {
     memset(&ap, 0, sizeof(ap));
     ap.q = dq; ap.k = L.crossK + cross_off; ap.v = L.crossV + cross_off; ap.H = H; ap.kv_T = w->Spad; ap.pos = nullptr; ap.T = d.n_audio_ctx;
     ap.scale_log2e = scale_log2e; ap.part_o = part_o; ap.part_ml = part_ml; ap.out_bf16 = dattn;
@@ -1004,6 +1068,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       TRY(ccx_launch_dec_attention(ctx, ap, B, ns, false, stream));
       TRY(partial_linear(ACT_COMBINE, L.Wco, L.bco, D, nullptr));
     }
+    }   // !xs_active
     // MLP.  OPTIONAL (CCX_DEC_FC1_GEMM_ROWS=n, off by default): with n rows and more the first linear runs through the tiled GEMM,
     // which shares the weight and activation tiles of a block through LDS where the skinny kernel re-reads them per 32-column
     // block out of L2: pipeline step 653.1 -> 647.6 ms at n = 256.  It is off because the GEMM sums K in another order than the
@@ -1107,6 +1172,7 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
     CCX_REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < w->d.n_vocab, "decoder_logits: token id %d out of range", tokens[i]);
   std::vector<int32_t> lens(B, T + 1);  // never leaves the prompt phase: every step feeds tokens[b][pos]
   // prompt buffer rows are `T` wide here
+  TRY(select_cross_path(w, B, stream));
   TRY(upload_decode_state(w, tokens, lens.data(), T, B, 0.f, 0, stream));
   const long V = w->d.n_vocab;
   w->cross_lds_pad = 0;   // single lane: the cross attention runs uncapped
@@ -1167,6 +1233,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   // prompts of 2 .. kPrefillMax tokens are prefilled in one pass (CCX_PREFILL=0: one decode step per prompt token, round 1's way)
   const int prefill_on = [] { const char* e = getenv("CCX_PREFILL"); return e ? atoi(e) : 1; }();     // read per call: tests flip it
   const bool prefill = prefill_on && max_pl >= 2 && max_pl <= ccx_whisper::kPrefillMax;
+  TRY(select_cross_path(w, B, stream));
   TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, temperature, seed, stream, prefill));
   // steps still to run after the (eager) first one: the prefill already covers the prompt AND takes the first sample below
   const int total_steps = prefill ? sample_len : max_pl - 1 + sample_len;
@@ -1245,7 +1312,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4), i};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8), i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

@@ -1,0 +1,117 @@
+"""GPU parity of the decode cross attention computed against the encoder output (csrc/cross_x.hip: expanded queries, ONE pass over
+xa for all heads, value projection afterwards) with a plain fp32 restatement of openai-whisper's MultiHeadAttention(x, xa) for one
+token: K = xa Wk^T, V = xa Wv^T + bv, softmax(q K^T / 8) V per head.  Through the C ABI (ccx_cross_attention_xa).
+Tolerance: rel-L2 <= 1e-2 per row (bf16 operands, fp32 accumulation), measured values in profiles/."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import within
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _reference(q, wk, wv, bv, xa, row_seq, H):
+    """fp32, explicit K/V (the reference's formulation); weights and xa as the kernel sees them (bf16-rounded)"""
+    D = 64 * H
+    out = torch.empty(q.shape[0], D)
+    for r in range(q.shape[0]):
+        x = xa[row_seq[r]].double()
+        k = x @ wk.double().T
+        v = x @ wv.double().T + bv.double()
+        for h in range(H):
+            sl = slice(64 * h, 64 * h + 64)
+            s = (k[:, sl] @ q[r, sl].double()) * 0.125
+            p = torch.softmax(s, dim=0)
+            out[r, sl] = (p @ v[:, sl]).float()
+    return out
+
+
+def _run(ccx_ctx, q, wk, wv, bv, xa, row_seq, H):
+    from clearconverse_amd import _lib
+    lib = _lib.load()
+    rows, D = q.shape
+    n_seq, S, _ = xa.shape
+    qd = q.contiguous().cuda()
+    xd = xa.to(torch.bfloat16).contiguous().cuda()
+    out = torch.empty(rows, D, device="cuda")
+    wk_h, wv_h, bv_h = (np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (wk, wv, bv))
+    rs = None if row_seq is None else (C.c_int * rows)(*[int(v) for v in row_seq])
+    ccx_ctx.check(lib.ccx_cross_attention_xa(ccx_ctx.handle, qd.data_ptr(), wk_h.ctypes.data, wv_h.ctypes.data, bv_h.ctypes.data,
+                                             xd.data_ptr(), rs, rows, n_seq, H, S, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                  "ccx_cross_attention_xa")
+    return out.cpu()
+
+
+def _case(seed, H, S, rows, n_seq, q_gain=1.0, row_seq=None):
+    g = torch.Generator().manual_seed(seed)
+    D = 64 * H
+    q = torch.randn(rows, D, generator=g) * q_gain
+    wk = _bf16_round(torch.randn(D, D, generator=g) / D ** 0.5)
+    wv = _bf16_round(torch.randn(D, D, generator=g) / D ** 0.5)
+    bv = torch.randn(D, generator=g) * 0.1
+    xa = _bf16_round(torch.randn(n_seq, S, D, generator=g))
+    rs = list(range(rows)) if row_seq is None else row_seq
+    return q, wk, wv, bv, xa, rs
+
+
+@pytest.mark.parametrize("H,S,rows", [(12, 1500, 5), (2, 1500, 19), (6, 1500, 3), (12, 100, 2), (4, 37, 3), (8, 16, 2), (12, 1499, 1)])
+def test_cross_attention_against_explicit_kv(ccx_ctx, H, S, rows):
+    q, wk, wv, bv, xa, rs = _case(100 + H + S, H, S, rows, rows, q_gain=2.0)
+    got = _run(ccx_ctx, q, wk, wv, bv, xa, None, H)
+    want = _reference(q, wk, wv, bv, xa, rs, H)
+    assert torch.isfinite(got).all()
+    for r in range(rows):
+        rel = float((got[r] - want[r]).norm() / want[r].norm())
+        within(f"cross attention against xa (H={H}): output rel-L2", rel, TOL, (S, r))
+
+
+def test_peaked_scores_and_the_repeat_pass(ccx_ctx):
+    """Scores far above the first tile's (the fixed softmax reference): p = exp2(t - m_ref) grows up to 2^100 without harm, and one key
+    whose score exceeds the first tile by MORE than that makes a wave repeat its tiles with the maximum it has seen.  Both must give the
+    reference's softmax (which is then a near one-hot on that key)."""
+    H, S = 12, 1500
+    for boost, name in ((6.0, "p up to ~2^60"), (40.0, "repeat pass")):
+        q, wk, wv, bv, xa, rs = _case(7, H, S, 3, 3)
+        # key 1001 of sequence 1 gets a feature vector aligned with head 5's expanded query; key 777 of sequence 2 with head 0's
+        for seq, key, h in ((1, 1001, 5), (2, 777, 0)):
+            qe = (q[seq, 64 * h:64 * h + 64] @ wk[64 * h:64 * h + 64, :])          # the head's expanded query [D]
+            xa[seq, key] = _bf16_round(qe / qe.norm() * boost * 4.0)
+        got = _run(ccx_ctx, q, wk, wv, bv, xa, None, H)
+        want = _reference(q, wk, wv, bv, xa, rs, H)
+        assert torch.isfinite(got).all(), name
+        for r in range(3):
+            within(f"cross attention against xa: peaked scores ({name}), rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), TOL, r)
+
+
+def test_rows_share_sequences_and_do_not_see_each_other(ccx_ctx):
+    """Prompt prefill: several rows per sequence (row_seq).  A row's output is bit-identical whatever else is in the launch."""
+    H, S = 12, 1500
+    rs = [0, 0, 0, 1, 2, 2, 1]
+    q, wk, wv, bv, xa, _ = _case(11, H, S, len(rs), 3, row_seq=rs)
+    got = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H)
+    want = _reference(q, wk, wv, bv, xa, rs, H)
+    for r in range(len(rs)):
+        within("cross attention against xa: rows mapped to sequences, rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), TOL, r)
+    for r in (1, 3, 6):
+        alone = _run(ccx_ctx, q[r:r + 1], wk, wv, bv, xa, [rs[r]], H)
+        assert torch.equal(alone[0], got[r]), r
+    again = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H)
+    assert torch.equal(again, got)
+
+
+def test_argument_errors(ccx_ctx):
+    from clearconverse_amd import _lib
+    q, wk, wv, bv, xa, rs = _case(1, 2, 64, 2, 2)
+    with pytest.raises(_lib.CcxError):
+        _run(ccx_ctx, q, wk, wv, bv, xa, [0, 5], 2)               # row mapped to a sequence that does not exist
+    q3, wk3, wv3, bv3, xa3, _ = _case(1, 3, 64, 1, 1)
+    with pytest.raises(_lib.CcxError):
+        _run(ccx_ctx, q3, wk3, wv3, bv3, xa3, None, 3)            # width 192 is not instantiated

@@ -163,7 +163,7 @@ def test_peak_normalize_matches_reference_formula(ccx_ctx, eps):
     assert bool((y[3, :64] == 0.0).all())        # silent row stays silent for both flavours (0 / 1e-8 = 0)
 
 
-def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(ccx_ctx):
+def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(ccx_ctx, monkeypatch):
     """The configuration bench.py TIMES by default, at full size: four batches of 32 x 30 s clips through
     `run_pinned_pipelined(span=4)` -- ONE 768-sequence decode group in two hipGraph lanes of 384 rows, two Whisper instances of
     768 windows sharing their log-mel / encoder workspaces (`ccx_whisper_share_encoder_scratch`), full small.en, full-depth
@@ -171,8 +171,10 @@ def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(cc
     back/api.py:1298), so (a) every batch must equal `run_pinned` of that batch alone (192-sequence groups in three lanes of 64):
     identical tokens, prompts, source picks, similarities, embeddings and separated waveforms bit for bit; log-probabilities
     bit for bit too if the lane width does not enter the arithmetic (reported), else to 2e-3 relative; (b) clips 0, 13 and 31 of
-    batch 2, run alone (6 sequences, small-batch decode path), give the same tokens, bit-identical embeddings / separated
-    waveforms and log-probabilities to 2e-3 relative (6 split-KV partials instead of one block per key range)."""
+    batch 2, run alone (6 sequences; CCX_CROSS_X_MIN_ROWS=1 keeps them on the cross-attention path of the large groups, the one
+    against the encoder output -- by default 6 sequences take the split-KV kernels, whose agreement to rounding
+    tests/test_whisper_gpu.py checks), give the same tokens, bit-identical embeddings / separated waveforms and log-probabilities
+    to 1e-4."""
     from clearconverse_amd.batch import BatchPipeline
     from clearconverse_amd.models import build_state_dicts, load_models
     B, sample_len, span = 32, 4, 4
@@ -207,6 +209,7 @@ def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(cc
         print("span-4 pipelined (2 x 384-row lanes) vs sequential (3 x 64-row lanes): log-probabilities",
               "bit-identical" if lp_bits else "equal to 2e-3 relative (not bit-identical)")
         full = pip[2]
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
         for bsel in (0, 13, 31):
             one = bp.run_pinned(batches[2][bsel:bsel + 1].contiguous(), debug=True)
             assert one["sims"] == full["sims"][2 * bsel:2 * bsel + 2], bsel
@@ -219,7 +222,7 @@ def test_configs3_pipelined_span4_full_size_equals_sequential_and_clips_alone(cc
             for j, i in enumerate(idx):
                 assert one["records"][j]["tokens"] == full["records"][i]["tokens"], (bsel, j)
                 lp = full["records"][i]["sum_logprob"]
-                assert abs(one["records"][j]["sum_logprob"] - lp) < 2e-3 * max(1.0, abs(lp)), (bsel, j)
+                assert abs(one["records"][j]["sum_logprob"] - lp) < 1e-4 * max(1.0, abs(lp)), (bsel, j)
     finally:
         for m in ("separator", "embedding_model", "diarization_embedder", "segmentation_vad", "segmentation_diar", "denoiser"):
             models[m].close()

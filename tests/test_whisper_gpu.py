@@ -165,6 +165,55 @@ def _check_greedy(dims, sd, m, xa, prompts, sample_len, tol):
     return res, n_exact_required
 
 
+def _oracle_accepts(orc, xa_row, prompt, result, sample_len, tol):
+    """every token of `result` is an eps-argmax of the oracle's filtered logits under teacher forcing"""
+    rules, orules = _rules()
+    toks = result["tokens"]
+    forced = toks + ([rules.eot] if len(toks) < sample_len else [])
+    seq, sampled = list(prompt), []
+    for i, t in enumerate(forced):
+        lg = R.apply_filters(orc.decoder_logits(torch.tensor([seq]), xa_row)[0, -1], sampled, orules)
+        assert float(lg[t]) >= float(lg.max()) - tol, (i, t, int(lg.argmax()), float(lg.max()) - float(lg[t]))
+        seq.append(t); sampled.append(t)
+
+
+def _two_paths_agree(name, orc, xa_row, prompt, ra, rb, sample_len, tol, bound=2e-3):
+    """The same window decoded by the two cross-attention formulations (split-KV kernels on K / V caches for decodes of <= 16
+    sequences, one pass over the encoder output for larger ones): equal tokens and log-probabilities to `bound` relative -- or,
+    where a near-tie tips the other way, both token strings must be eps-argmax strings of the oracle.  Returns 1 for a divergence."""
+    if ra["tokens"] == rb["tokens"]:
+        within(name, abs(ra["sum_logprob"] - rb["sum_logprob"]) / max(1.0, abs(rb["sum_logprob"])), bound)
+        assert abs(ra["no_speech_prob"] - rb["no_speech_prob"]) <= 1e-4 + 2e-3 * rb["no_speech_prob"]
+        return 0
+    _oracle_accepts(orc, xa_row, prompt, ra, sample_len, tol)
+    _oracle_accepts(orc, xa_row, prompt, rb, sample_len, tol)
+    return 1
+
+
+def _batch_mates(m, dims, sd, dev, n, prompts, reps, sample_len, monkeypatch, lanes=None):
+    """4 windows decoded alone and as `reps` copies in one batch.  On ONE cross-attention path (CCX_CROSS_X_MIN_ROWS=1 puts the four
+    on the path of the large batch) a sequence's tokens and log-probability must not depend on its batch mates, lanes or graph; the
+    default small-batch path (split-KV kernels) must agree with it to rounding."""
+    m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
+    a_small = m.decode_greedy(prompts, sample_len=sample_len)
+    monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
+    a = m.decode_greedy(prompts, sample_len=sample_len)
+    monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
+    big = dev.repeat(reps, 1).contiguous()
+    m.log_mel(big, n * reps); m.encode(4 * reps)
+    if lanes:
+        monkeypatch.setenv("CCX_DEC_LANES", str(lanes))
+    b = m.decode_greedy(prompts * reps, sample_len=sample_len)
+    for i in range(4 * reps):
+        assert b[i]["tokens"] == a[i % 4]["tokens"], i
+        assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-4, i
+    orc = _oracle(dims, sd)
+    div = sum(_two_paths_agree("whisper mini: |sum_logprob K/V-cache path - X-stream path| / max(1, |.|)", orc, xa[i:i + 1], prompts[i],
+                               a_small[i], a[i], sample_len, 0.05) for i in range(4))
+    assert div <= 1
+    return a, b, xa
+
+
 def test_greedy_mini(mini):
     dims, sd, m = mini
     rules, _ = _rules()
@@ -256,7 +305,8 @@ def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
     reference's own pattern is one window per decode, back/api.py:1286-1292).  It repeats the two launches it replaces operation
     for operation, so at full small.en size the tokens, log-probabilities and no-speech probabilities of 1, 5 and 16 sequences
     (prompts of different lengths, stepwise prompt feeding and prefill, greedy and sampled) must equal the two-launch path exactly;
-    a 20-sequence batch (large-batch path, never fused) decodes the same tokens for the same windows."""
+    a 20-sequence batch (cross attention against the encoder output, never fused) agrees to rounding: the same tokens, or -- at a
+    near-tie of these gain-3 weights -- two eps-argmax strings of the oracle."""
     from clearconverse_amd.whisper import WhisperModel
     dims = WhisperDims.small_en()
     sd = synthetic_whisper_state_dict(dims, seed=3, gain=3.0)
@@ -265,7 +315,7 @@ def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
         rules, _ = _rules()
         clips, n, dev = _clips([30.0, 9.0, 4.0, 17.5, 2.0] * 4)
         m.log_mel(dev, n)
-        m.encode(20)
+        xa = m.encode(20, return_xa=True).cpu()
         base = [[rules.sot], [rules.sot_prev, 1212, 318, rules.sot], [rules.sot_prev, 464, 1917, 11, 262, rules.sot], [rules.sot], [rules.sot_prev, 50, rules.sot]]
         for B in (1, 5, 16):
             prompts = [base[i % 5] for i in range(B)]
@@ -282,12 +332,20 @@ def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
         monkeypatch.setenv("CCX_FUSE_CROSS_Q", "1")
         small = m.decode([base[i % 5] for i in range(16)], sample_len=7)
         large = m.decode([base[i % 5] for i in range(20)], sample_len=7)
-        for i in range(16):
-            assert small[i]["tokens"] == large[i]["tokens"], i
-            # (gain-3 weights: sharper softmaxes than the other path-equivalence tests, whose bound is 2e-3; 6 split-KV partials against
-            #  one block per key range -- the same two kernels as before the fusion)
-            within("whisper small.en gain 3: |sum_logprob small-batch - large-batch path| / max(1, |.|)",
-                   abs(small[i]["sum_logprob"] - large[i]["sum_logprob"]) / max(1.0, abs(large[i]["sum_logprob"])), 5e-3, i)
+        # (gain-3 weights: sharper softmaxes and smaller margins than the other path-equivalence tests, whose bound is 2e-3; the 20
+        #  sequences take the cross attention against the encoder output, the 16 the split-KV kernels on K / V caches)
+        orc = _oracle(dims, sd)
+        div = sum(_two_paths_agree("whisper small.en gain 3: |sum_logprob K/V-cache path - X-stream path| / max(1, |.|)", orc, xa[i:i + 1],
+                                   base[i % 5], small[i], large[i], 7, 0.15, bound=1.5e-2) for i in range(16))
+        assert div <= 4, div
+        # ... and each of the two against the oracle under teacher forcing (these weights amplify every rounding ~3x per layer)
+        _, orules = _rules()
+        for i in range(5):
+            for path, res in (("K/V-cache", small[i]), ("X-stream", large[i])):
+                forced = res["tokens"] + ([rules.eot] if len(res["tokens"]) < 7 else [])
+                o = R.greedy_decode(orc, xa[i:i + 1], [base[i]], orules, sample_len=7, forced=[forced])[0]
+                within(f"whisper small.en gain 3: |sum_logprob {path} path - oracle (teacher forced)| / max(1, |oracle|)",
+                       abs(o.sum_logprob - res["sum_logprob"]) / max(1.0, abs(o.sum_logprob)), 2e-2, i)
     finally:
         m.close()
 
@@ -326,9 +384,9 @@ def test_transcribe_call_surface(mini):
         m.transcribe(audio, temperature=(0.0, 0.2, 0.4))      # fallback schedules: not implemented, must fail loudly
 
 
-def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
-    """B > 16 switches the decode chain to the stand-alone resolve+LayerNorm kernel and multi-tile skinny
-    GEMMs; the tokens of a sequence must not depend on how many batch mates it has."""
+def test_large_batch_decode_path_matches_small_batch(ccx_ctx, monkeypatch):
+    """More than 16 sequences switch the decode chain to the stand-alone resolve+LayerNorm kernel, multi-tile skinny GEMMs and the
+    cross attention against the encoder output (cross_x.hip); the tokens of a sequence must not depend on how many batch mates it has."""
     from clearconverse_amd.whisper import WhisperModel
     dims = WhisperDims.mini(n_layer=2, n_state=128)
     sd = synthetic_whisper_state_dict(dims, seed=3)
@@ -336,16 +394,8 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx):
     try:
         rules, _ = _rules()
         clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
-        small = dev
-        m.log_mel(small, n); m.encode(4)
         prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
-        a = m.decode_greedy(prompts, sample_len=16)
-        big = small.repeat(10, 1).contiguous()                      # 40 sequences: the same 4 windows, 10 times
-        m.log_mel(big, n * 10); m.encode(40)
-        b = m.decode_greedy(prompts * 10, sample_len=16)
-        for i in range(40):
-            assert b[i]["tokens"] == a[i % 4]["tokens"], i
-            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-3
+        _batch_mates(m, dims, sd, dev, n, prompts, 10, 16, monkeypatch)     # 40 sequences: the same 4 windows, 10 times
     finally:
         m.close()
 
@@ -360,23 +410,15 @@ def test_lane_of_256_rows_and_more_matches_small_batch(ccx_ctx, monkeypatch):
     try:
         rules, _ = _rules()
         clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
-        m.log_mel(dev, n); m.encode(4)
         prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
-        a = m.decode_greedy(prompts, sample_len=12)
-        big = dev.repeat(66, 1).contiguous()
-        m.log_mel(big, n * 66); m.encode(264)
-        monkeypatch.setenv("CCX_DEC_LANES", "1")
-        b = m.decode_greedy(prompts * 66, sample_len=12)
-        for i in range(264):
-            assert b[i]["tokens"] == a[i % 4]["tokens"], i
-            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-3
+        _batch_mates(m, dims, sd, dev, n, prompts, 66, 12, monkeypatch, lanes=1)
     finally:
         m.close()
 
 
 def test_uneven_lane_partition_matches_small_batch(ccx_ctx, monkeypatch):
-    """100 sequences in 3 lanes are cut 48 / 48 / 4: the last lane takes the small-batch kernel path, the others the
-    large-batch one, each on its own stream and graph -- every sequence must still decode exactly as in a batch of 4."""
+    """100 sequences in 3 lanes are cut 48 / 48 / 4: the last lane takes the <= 16-row kernels of the linears, the others the
+    large-batch ones, each on its own stream and graph -- every sequence must still decode exactly as in a batch of 4."""
     from clearconverse_amd.whisper import WhisperModel
     dims = WhisperDims.mini(n_layer=2, n_state=128)
     sd = synthetic_whisper_state_dict(dims, seed=3)
@@ -384,16 +426,8 @@ def test_uneven_lane_partition_matches_small_batch(ccx_ctx, monkeypatch):
     try:
         rules, _ = _rules()
         clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
-        m.log_mel(dev, n); m.encode(4)
         prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, rules.sot]]
-        a = m.decode_greedy(prompts, sample_len=12)
-        big = dev.repeat(25, 1).contiguous()
-        m.log_mel(big, n * 25); m.encode(100)
-        monkeypatch.setenv("CCX_DEC_LANES", "3")
-        b = m.decode_greedy(prompts * 25, sample_len=12)
-        for i in range(100):
-            assert b[i]["tokens"] == a[i % 4]["tokens"], i
-            assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-4
+        _batch_mates(m, dims, sd, dev, n, prompts, 25, 12, monkeypatch, lanes=3)
     finally:
         m.close()
 
@@ -455,11 +489,20 @@ def test_prompt_prefill_equals_stepwise_prompt_feeding(ccx_ctx, monkeypatch):
         s0 = m.decode(prompts, sample_len=8, temperature=0.7, seed=11)
         monkeypatch.delenv("CCX_PREFILL")
         assert [r["tokens"] for r in s1] == [r["tokens"] for r in s0]
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")                            # the four on the large batch's cross-attention path
+        ax = m.decode_greedy(prompts, sample_len=10)
+        monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
+        orc = _oracle(dims, sd)
+        for i in range(4):
+            _two_paths_agree("whisper mini: |sum_logprob K/V-cache path - X-stream path| / max(1, |.|)", orc, xa[i:i + 1], prompts[i], a[i], ax[i], 10, 0.08)
+            _oracle_accepts(orc, xa[i:i + 1], prompts[i], ax[i], 10, 0.08)        # prefill rows through the X-stream kernel (row -> sequence map)
         big = dev.repeat(10, 1).contiguous()
         m.log_mel(big, n * 10); m.encode(40)
         c = m.decode_greedy(prompts * 10, sample_len=10)                          # 40 x 16 = 640 prefill rows, then lanes
         for i in range(40):
-            assert c[i]["tokens"] == a[i % 4]["tokens"], i
+            assert c[i]["tokens"] == ax[i % 4]["tokens"], i
+            assert abs(c[i]["sum_logprob"] - ax[i % 4]["sum_logprob"]) < 1e-4, i
+        m.log_mel(dev, n); m.encode(4)
         one = m.decode_greedy([prompts[1]], sample_len=1)                         # sample_len 1: the prefill's own sample is the only one
         assert one[0]["tokens"] == a[1]["tokens"][:1]
     finally:
