@@ -413,9 +413,11 @@ def main():
     # The probe decodes a group that is 16 rows per lane SMALLER than the timed one (768 -> 736 sequences = 2 lanes of 368): the same
     # kernels and lane count, but a launch shape of its own, so that rocprofv3's per-grid summary of this command
     # (tools/kernel_trace_by_grid.py, profiles/) shows exactly these launches in a row of their own next to `roofline.avg_launch_us`.
-    nl_real = 2 if Bd >= 640 else (3 if Bd >= 144 else (2 if Bd >= 96 else 1))
+    def n_lanes(b):                       # as ccx_whisper_decode cuts a group into lanes
+        return (3 if xstream else 2) if b >= 640 else (3 if b >= 144 else (2 if b >= 96 else 1))
+    nl_real = n_lanes(Bd)
     Bp = Bd - 16 * nl_real
-    if (2 if Bp >= 640 else (3 if Bp >= 144 else (2 if Bp >= 96 else 1))) != nl_real or nl_real == 1:
+    if n_lanes(Bp) != nl_real or nl_real == 1:
         Bp = Bd
     os.environ["CCX_NO_GRAPH"] = "1"
     ctx.prof_enable(True)

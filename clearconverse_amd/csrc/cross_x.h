@@ -14,7 +14,9 @@
 struct XsParams {
   const float* q;        // [rows][D] f32 queries (bias included, not scaled)
   const bf16_t* WkT;     // [H][D][64]: WkT[h][f][d] = Wk[h*64 + d][f]   (cross_attn.key.weight re-laid per head)
-  bf16_t* xq;            // [rows][H][D]: expanded queries (xq_expand) -> normalised contexts sum_j p_hj xa_j (xs_stream), in place
+  bf16_t* xq;            // [rows][H][D]: expanded queries
+  float* part_o;         // [rows][XS_SPLIT][H][D]: unnormalised contexts of each key half (ccx_xs_part_o_elems)
+  float* part_ml;        // [rows][XS_SPLIT][16][2]: reference maximum and denominator of each key half (ccx_xs_part_ml_elems)
   const bf16_t* X;       // [sequences][x_seq_stride]: encoder output rows [S][D] per sequence
   long x_seq_stride;     // elements between sequences
   const int* row_seq;    // row -> sequence (prompt prefill: several rows per sequence); null: identity
@@ -23,9 +25,14 @@ struct XsParams {
   bf16_t* out;           // [rows][D] attention output (input of cross_attn.out)
   int rows, H, S, D;
   float scale_log2e;     // (d_head ^ -0.25)^2 * log2(e)
+  int lds_pad;           // LDS the streaming blocks claim without using it (occupancy cap while decode lanes overlap)
 };
 
-// the three launches of one layer's cross attention: q' = expand(q); ctx = softmax(q' xa^T) xa; out = ctx Wv^T + bv
+// key ranges per row, each streamed by a block of its own (fixed: a row's arithmetic must not depend on the launch)
+#define XS_SPLIT 2
+static inline size_t ccx_xs_part_o_elems(size_t rows, int H, int D) { return rows * XS_SPLIT * (size_t)H * D; }
+static inline size_t ccx_xs_part_ml_elems(size_t rows) { return rows * XS_SPLIT * 16 * 2; }
+// the three launches of one layer's cross attention: q' = expand(q); partial contexts of the key halves; out = merge(partials) Wv^T + bv
 int ccx_launch_xs_cross_attention(ccx_ctx* ctx, const XsParams& p, hipStream_t stream);
 // widths the kernels are instantiated for
 bool ccx_xs_supported(int D, int H);

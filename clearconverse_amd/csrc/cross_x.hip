@@ -5,17 +5,7 @@
 //   dec_xq_expand_kernel   q'[row][h][:] = q[row][h*64 .. +64] Wk_h                        (64 -> D per head; 1.2 MB of weights)
 //   dec_xs_stream_kernel   ctx[row][h][:] = sum_j softmax_j(q'[row][h] . xa_j * scale) xa_j (ONE pass over the sequence's xa: the HBM-bound part)
 //   dec_xv_project_kernel  out[row][h*64 .. +64] = ctx[row][h] Wv_h^T + bv                 (D -> 64 per head)
-// dec_xs_stream_kernel: one block per row (sequence), four waves, one wave per SIMD with the whole register file (accumulators for all
-// heads x all D features: D/4 registers).  A wave owns every fourth 16-key tile of xa and is a self-contained pipeline:
-//   1. tile t + 1 is requested (D/32 16-byte loads per lane: lane = key l%16, feature chunk l/16 -- the MFMA A-operand image of
-//      S^T = xa_tile q'^T, so the scores need no staging at all),
-//   2. S^T [16 keys x 16 heads] = D/32 v_mfma_f32_16x16x32_bf16 against q' (LDS, B operand, heads on the N index),
-//   3. base-2 softmax against a FIXED reference (the maximum of the wave's first tile; see the loop): no accumulator rescale, ever,
-//   4. the tile goes to the wave's private LDS strip as it came ([key][feature], 32 B of row padding), and comes back TRANSPOSED
-//      through ds_read_b64_tr_b16 as the A operand of ctx^T [16 features x 16 heads] += xa_tile^T p^T -- D/16 v_mfma_f32_16x16x16_bf16,
-//      whose B operand (4 keys x 1 head per lane) is exactly what the S^T accumulator holds after exp2: no transpose of p either.
-// No block-level barrier inside the loop; the four waves' partial (max, sum, ctx) are merged through LDS at the end in a fixed
-// order (deterministic: a row's numbers depend on nothing but its own q' and xa).
+// (the kernels carry their own descriptions)
 #include "cross_x.h"
 
 namespace {
@@ -62,38 +52,83 @@ __global__ __launch_bounds__(256) void dec_xq_expand_kernel(XsParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// out = ctx Wv^T + bv per head.  Block = (head, 16 rows); wave w owns the head's output features [16 w, 16 w + 16).
-// MFMA roles: A = Wv rows [out feature][f] (M), B = ctx^T [f][row] (N = rows), K = D.
+// out = ctx Wv^T + bv per head, ctx = the merged key-half partials of dec_xs_stream_kernel.  Block = (head, 16 rows): all 256
+// threads merge the head's contexts of the 16 rows into LDS as bf16 (ctx = (o0 w0 + o1 w1) / (l0 w0 + l1 w1), w_s = exp2(m_s - max m):
+// the flash-decoding merge, in a fixed order), then wave w owns the head's output features [16 w, 16 w + 16).
+// MFMA roles: A = Wv rows [out feature][f] (M), B = ctx^T [f][row] (N = rows, from LDS), K = D.
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(256) void dec_xv_project_kernel(XsParams p) {
-  constexpr int NKS = D / 32;
+  constexpr int NKS = D / 32, RSB = 2 * D + 16;
+  __shared__ __attribute__((aligned(16))) char ctx_s[16 * RSB];
   const int h = blockIdx.x, r0 = blockIdx.y * 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  int row = r0 + n;
-  const bool live = row < p.rows;
-  if (!live) row = p.rows - 1;
   const int o0 = h * 64 + wave * 16;
+  // weights first: they do not depend on the merge
   const bf16_t* wsrc = p.Wv + (long)(o0 + n) * D + g * 8;
-  const bf16_t* csrc = p.xq + ((long)row * p.H + h) * D + g * 8;
-  f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
   constexpr int CH = NKS % 6 == 0 ? 6 : 4;      // k-steps requested together
   static_assert(NKS % CH == 0, "D must be a multiple of 128");
+  bf16x8 a[CH];
 #pragma unroll
-  for (int c0 = 0; c0 < NKS; c0 += CH) {
-    bf16x8 a[CH], b[CH];
+  for (int k = 0; k < CH; k++) a[k] = *(const bf16x8*)(wsrc + k * 32);
+  {
+    const int rr = threadIdx.x >> 4, c = threadIdx.x & 15;       // row of the tile, float4 column phase
+    int row = r0 + rr;
+    if (row >= p.rows) row = p.rows - 1;
+    float m[XS_SPLIT], l[XS_SPLIT], wgt[XS_SPLIT];
+    float mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
-      a[k] = *(const bf16x8*)(wsrc + (c0 + k) * 32);
-      b[k] = *(const bf16x8*)(csrc + (c0 + k) * 32);
+    for (int s2 = 0; s2 < XS_SPLIT; s2++) {
+      const float2 ml = *(const float2*)(p.part_ml + (((long)row * XS_SPLIT + s2) * 16 + h) * 2);
+      m[s2] = ml.x; l[s2] = ml.y;
+      mx = fmaxf(mx, ml.x);
     }
+    float den = 0.f;
 #pragma unroll
-    for (int k = 0; k < CH; k++) {
-      if (k & 1) cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b[k], cb, 0, 0, 0);
-      else ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b[k], ca, 0, 0, 0);
+    for (int s2 = 0; s2 < XS_SPLIT; s2++) {
+      wgt[s2] = __builtin_amdgcn_exp2f(m[s2] - mx);               // an empty half has m = -inf, l = 0: weight 0
+      den = fmaf(l[s2], wgt[s2], den);
+    }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int s2 = 0; s2 < XS_SPLIT; s2++) wgt[s2] *= inv;
+    const float* src = p.part_o + (((long)row * XS_SPLIT) * p.H + h) * D;
+    const long sstride = (long)p.H * D;
+#pragma unroll
+    for (int k = 0; k < D / 64; k++) {
+      const int f = (c + 16 * k) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < XS_SPLIT; s2++) {
+        const float4 o = *(const float4*)(src + s2 * sstride + f);
+        v.x = fmaf(o.x, wgt[s2], v.x); v.y = fmaf(o.y, wgt[s2], v.y); v.z = fmaf(o.z, wgt[s2], v.z); v.w = fmaf(o.w, wgt[s2], v.w);
+      }
+      *(u32x2*)(ctx_s + rr * RSB + f * 2) = (u32x2){pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
     }
   }
-  if (live) {
+  __syncthreads();
+  const char* csrc = ctx_s + n * RSB + g * 16;
+  f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c0 = 0; c0 < NKS; c0 += CH) {
+    bf16x8 an[CH];
+    if (c0 + CH < NKS) {
+#pragma unroll
+      for (int k = 0; k < CH; k++) an[k] = *(const bf16x8*)(wsrc + (c0 + CH + k) * 32);
+    }
+#pragma unroll
+    for (int k = 0; k < CH; k++) {
+      const bf16x8 b = *(const bf16x8*)(csrc + (c0 + k) * 64);
+      if (k & 1) cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b, cb, 0, 0, 0);
+      else ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k], b, ca, 0, 0, 0);
+    }
+    if (c0 + CH < NKS) {
+#pragma unroll
+      for (int k = 0; k < CH; k++) a[k] = an[k];
+    }
+  }
+  const int row = r0 + n;
+  if (row < p.rows) {
     const float4 bias = *(const float4*)(p.bv + o0 + g * 4);
     const float v0 = ca[0] + cb[0] + bias.x, v1 = ca[1] + cb[1] + bias.y, v2 = ca[2] + cb[2] + bias.z, v3 = ca[3] + cb[3] + bias.w;
     *(u32x2*)(p.out + (long)row * D + o0 + g * 4) = (u32x2){pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
@@ -106,153 +141,161 @@ __global__ __launch_bounds__(256) void dec_xv_project_kernel(XsParams p) {
 namespace {
 template <int D>
 struct XsGeom {
-  static constexpr int NKS = D / 32;           // k-steps of the score MFMAs (features)
-  static constexpr int NMT = D / 16;           // M tiles of the context MFMAs (features)
-  static constexpr int RS = 2 * D + 32;        // bytes per staged key row: +32 makes the transposed reads of 8 rows hit 64 different banks
-  static constexpr int RSQ = 2 * D + 16;       // bytes per q' row
-  static constexpr int STRIP = 16 * RS;        // one wave's staging strip
-  static constexpr int Q_OFF = 4 * STRIP;
-  static constexpr int ML_OFF = Q_OFF + 16 * RSQ;
-  static constexpr int LDS = ML_OFF + 2 * 4 * 16 * 4;
-  static constexpr int CROW = D + 4;           // floats per head row of the merge buffer (aliases the strips)
-  static_assert(16 * CROW * 4 <= 4 * STRIP, "merge buffer must fit the staging strips");
+  static constexpr int FW = D / 4;             // features per wave
+  static constexpr int NKS = FW / 32;          // k-steps of a wave's partial scores
+  static constexpr int NMT = FW / 16;          // M tiles of a wave's context slice
+  static constexpr int PF = 4;                 // key tiles a wave keeps in flight
+  static constexpr int RS = 2 * FW + 32;       // bytes per staged key row: +32 makes the transposed reads of 8 rows hit 64 different banks
+  static constexpr int STRIP = 16 * RS;        // one wave's staging strip (private: no barrier)
+  static constexpr int S_OFF = 4 * STRIP;      // partial-score exchange: [2 buffers][4 waves][64 lanes] f32x4
+  static constexpr int LDS = S_OFF + 2 * 4 * 1024;
 };
 }  // namespace
 
+// One block per (row, key half): XS_SPLIT = 2 blocks per sequence, ALWAYS -- a CU pulls ~25 GB/s whatever its occupancy, so the kernel
+// takes as long as the CU with the most bytes: 384 rows as 384 blocks leave half the CUs with two rows and half with one (217 us), as
+// 768 half-rows every CU gets three (the split is fixed so that a row's arithmetic never depends on the launch).  Two blocks per CU.
+// The four waves work on the SAME 16-key tile of xa, each on its quarter of the
+// D features (wave w: features [w D/4, (w+1) D/4)):
+//   1. the wave's quarter of the tile is requested PF = 4 tiles ahead into named register images (D/128 16-byte loads per lane and
+//      tile: lane = key l%16, feature chunk l/16 -- the MFMA A-operand image of S^T = xa_tile q'^T; the block's loads of one tile
+//      cover 24 KB of contiguous memory; cacheable loads: with the non-temporal hint the two 64-byte halves of a line, which two
+//      consecutive instructions ask for, cost 15 % of the rate),
+//   2. partial scores over the wave's features: D/128 v_mfma_f32_16x16x32_bf16 against its slice of q' (registers, loaded once),
+//   3. the four partial S^T [16 keys x 16 heads] meet in LDS (one barrier per tile, two buffers) and every wave adds them in the
+//      same order, so all four hold the same scores and run the same softmax: base 2, against a FIXED reference (the maximum of
+//      the row's first tile, see below) -- nothing is ever rescaled and the waves never exchange anything else,
+//   4. the wave's quarter tile goes to its private LDS strip as it came ([key][feature], 32 B of row padding) and comes back
+//      TRANSPOSED through ds_read_b64_tr_b16 as the A operand of ctx^T [16 features x 16 heads] += xa_tile^T p^T -- D/64
+//      v_mfma_f32_16x16x16_bf16 whose B operand (4 keys x 1 head per lane) is exactly what the S^T accumulator holds after exp2.
+// ~200 registers, 35 KB of LDS: two blocks per CU, 8 waves x 4 tiles x 6 KB = 192 KB of loads in flight per CU.
+// The halves' partials (contexts relative to their own reference, reference, denominator) are merged by dec_xv_project_kernel.
+// Deterministic: a row's numbers depend on nothing but its own q' and xa.
 template <int D>
-__global__ __launch_bounds__(256, 1) void dec_xs_stream_kernel(XsParams p) {
+__global__ __launch_bounds__(256, 2) void dec_xs_stream_kernel(XsParams p) {
   using G = XsGeom<D>;
-  constexpr int NKS = G::NKS, NMT = G::NMT, RS = G::RS, RSQ = G::RSQ;
+  constexpr int FW = G::FW, NKS = G::NKS, NMT = G::NMT, PF = G::PF, RS = G::RS;
   extern __shared__ __attribute__((aligned(16))) char xs_smem[];
-  const int row = blockIdx.x;
+  const int row = blockIdx.x / XS_SPLIT, sp = blockIdx.x % XS_SPLIT;
   const int seq = p.row_seq ? p.row_seq[row] : row;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int H = p.H, S = p.S;
   char* strip = xs_smem + wave * G::STRIP;
-  char* qlds = xs_smem + G::Q_OFF;
-  float* mw = (float*)(xs_smem + G::ML_OFF);
-  float* lw = mw + 64;
+  char* sbuf = xs_smem + G::S_OFF;
 
-  const bf16_t* Xp = p.X + (long)seq * p.x_seq_stride;
-  const int NT = (S + 15) >> 4;
-  const int n_w = (NT - wave + 3) >> 2;          // tiles wave, wave + 4, ...
+  const bf16_t* Xp = p.X + (long)seq * p.x_seq_stride + wave * FW + g * 8;
+  const int NTall = (S + 15) >> 4;
+  const int T0 = NTall * sp / XS_SPLIT, NT = NTall * (sp + 1) / XS_SPLIT;      // this block's key tiles [T0, NT)
 
-  bf16x8 XA[NKS];
-  auto load_tile = [&](int t) {
+  bf16x8 img[PF][NKS];
+  auto load_tile = [&](bf16x8 (&X)[NKS], int t) {
     int key = t * 16 + r;
     key = key < S ? key : S - 1;                 // the last tile's missing keys re-read the last row; their p is 0
-    const bf16_t* src = Xp + (long)key * D + g * 8;
+    const bf16_t* src = Xp + (long)key * D;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ks++) XA[ks] = __builtin_nontemporal_load((const bf16x8*)(src + ks * 32));
+    for (int ks = 0; ks < NKS; ks++) X[ks] = *(const bf16x8*)(src + ks * 32);
   };
-  if (n_w > 0) load_tile(wave);
+#pragma unroll
+  for (int j = 0; j < PF; j++)
+    if (T0 + j < NT) load_tile(img[j], T0 + j);
 
-  // q' of this row -> LDS (heads >= H: zero rows)
+  // the wave's slice of q' (B operand of the scores: head r, feature chunk g); heads >= H: zero
+  bf16x8 qf[NKS];
   {
-    bf16_t* xq_row = p.xq + (long)row * H * D;
-    constexpr int CPR = D / 8;                   // 16-byte chunks per head row
-    for (int i = threadIdx.x; i < 16 * CPR; i += 256) {
-      const int hh = i / CPR, c = i - hh * CPR;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (hh < H) v = *(const u32x4*)(xq_row + (long)hh * D + c * 8);
-      *(u32x4*)(qlds + hh * RSQ + c * 16) = v;
+    const bf16_t* qsrc = p.xq + ((long)row * H + (r < H ? r : 0)) * D + wave * FW + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      qf[ks] = *(const bf16x8*)(qsrc + ks * 32);
+      if (r >= H) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  __syncthreads();
 
   f32x4 acc[NMT];
   float m_ref = -INFINITY, m_seen = -INFINITY, l_part = 0.f;
-  const char* q_rd = qlds + r * RSQ + g * 16;                                  // B operand of the scores: head r, feature chunk g
   char* st_wr = strip + r * RS + g * 16;                                       // staging write: key r, feature chunk g
   const char* tr_rd = strip + (g * 4 + (r >> 2)) * RS + (r & 3) * 8;           // transposed read: lane 4q+p -> key 4g+q, features 4p..4p+3
+  char* s_wr = sbuf + wave * 1024 + lane * 16;
+  const char* s_rd = sbuf + lane * 16;
   const float scale = p.scale_log2e;
 
-  // Softmax reference: the maximum of the wave's FIRST tile (per head), never moved -- the accumulators (D/4 AccVGPRs, which the
-  // VALU cannot touch) are never rescaled.  p = exp2(t - m_ref) may then exceed 1; fp32 / bf16 carry it up to 2^127, and numerator
-  // and denominator share the reference, so the result is exact.  Should a later tile exceed the reference by more than 2^100
-  // (an attention peak of e^69 over the first 16 keys: unseen), the wave repeats its tiles once with the maximum it then knows.
+  auto tile = [&](const bf16x8 (&X)[NKS], int t, bool first) {
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      if (ks & 1) sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[ks], sb, 0, 0, 0);
+      else sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[ks], sa, 0, 0, 0);
+    }
+    const int boff = (t & 1) * 4096;
+    *(f32x4*)(s_wr + boff) = NKS > 1 ? sa + sb : sa;
+    // stage the quarter tile as it is (read back transposed below): private strip, the wave's own LDS operations stay in order
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) *(bf16x8*)(st_wr + ks * 64) = X[ks];
+    __syncthreads();
+    const f32x4 s0 = *(const f32x4*)(s_rd + boff), s1 = *(const f32x4*)(s_rd + boff + 1024), s2 = *(const f32x4*)(s_rd + boff + 2048),
+                s3 = *(const f32x4*)(s_rd + boff + 3072);
+    const f32x4 sc = (s0 + s1) + (s2 + s3);
+    // lane: head r, keys 16 t + 4 g + j
+    float tv[4];
+    const int key0 = t * 16 + g * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) tv[j] = key0 + j < S ? sc[j] * scale : -INFINITY;
+    float tmax = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+    tmax = fmaxf(tmax, lane_xor16(tmax));
+    tmax = fmaxf(tmax, lane_xor32(tmax));
+    m_seen = fmaxf(m_seen, tmax);
+    if (first) m_ref = tmax;                     // the row's first tile always holds live keys
+    float pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pv[j] = __builtin_amdgcn_exp2f(tv[j] - m_ref);
+    l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+    const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+    const bf16x4 pb = __builtin_bit_cast(bf16x4, pp);
+#pragma unroll
+    for (int mt = 0; mt < NMT; mt++) {
+      const bf16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tr_rd + mt * 32));
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, pb, acc[mt], 0, 0, 0);
+    }
+  };
+
+  // Softmax reference: the maximum of the row's FIRST tile (per head), never moved -- the accumulators are never rescaled.
+  // p = exp2(t - m_ref) may then exceed 1; fp32 / bf16 carry it up to 2^127, and numerator and denominator share the reference, so the
+  // result is exact.  Should a later tile exceed the reference by more than 2^100 (an attention peak of e^69 over the first 16 keys:
+  // unseen), the block repeats the row once with the maximum it then knows (every wave holds the same scores: a uniform decision).
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
       if (__builtin_amdgcn_ballot_w64(m_seen > m_ref + 100.f) == 0ull) break;
       m_ref = m_seen;
-      if (n_w > 0) load_tile(wave);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PF; j++)
+        if (T0 + j < NT) load_tile(img[j], T0 + j);
     }
     l_part = 0.f;
 #pragma unroll
     for (int mt = 0; mt < NMT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // ONE register image of a tile: scores straight out of it, then it goes to the strip and its registers take the next tile's
-    // loads, which fly under the context MFMAs of this one (24 KB per wave in flight almost all the time: 24 MB over the chip).
-    for (int i = 0; i < n_w; i++) {
-      const int t = wave + 4 * i;
-      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = T0; t0 < NT; t0 += PF) {
 #pragma unroll
-      for (int ks = 0; ks < NKS; ks++) {
-        const bf16x8 qf = *(const bf16x8*)(q_rd + ks * 64);
-        if (ks & 1) sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XA[ks], qf, sb, 0, 0, 0);
-        else sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XA[ks], qf, sa, 0, 0, 0);
-      }
-      // stage the tile as it is (read back transposed below); its registers are free for the next tile
-#pragma unroll
-      for (int ks = 0; ks < NKS; ks++) *(bf16x8*)(st_wr + ks * 64) = XA[ks];
-      if (i + 1 < n_w) load_tile(t + 4);
-      // lane: head r, keys 16 t + 4 g + j
-      float tv[4];
-      const int key0 = t * 16 + g * 4;
-#pragma unroll
-      for (int j = 0; j < 4; j++) tv[j] = key0 + j < S ? (sa[j] + sb[j]) * scale : -INFINITY;
-      float tmax = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
-      tmax = fmaxf(tmax, lane_xor16(tmax));
-      tmax = fmaxf(tmax, lane_xor32(tmax));
-      m_seen = fmaxf(m_seen, tmax);
-      if (i == 0 && pass == 0) m_ref = tmax;     // a wave's first tile always holds live keys
-      float pv[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) pv[j] = __builtin_amdgcn_exp2f(tv[j] - m_ref);
-      l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-      const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
-      const bf16x4 pb = __builtin_bit_cast(bf16x4, pp);
-#pragma unroll
-      for (int mt = 0; mt < NMT; mt++) {
-        const bf16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tr_rd + mt * 32));
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, pb, acc[mt], 0, 0, 0);
+      for (int j = 0; j < PF; j++) {
+        const int t = t0 + j;
+        if (t < NT) {
+          tile(img[j], t, pass == 0 && t == T0);
+          if (t + PF < NT) load_tile(img[j], t + PF);
+        }
       }
     }
   }
 
-  // ---- merge the four waves (fixed order) ----
+  // the block's partial: unnormalised contexts of its key range (relative to m_ref), its reference maximum and denominator
   float l_head = l_part;
   l_head += lane_xor16(l_head);
   l_head += lane_xor32(l_head);
-  if (g == 0) { mw[wave * 16 + r] = m_ref; lw[wave * 16 + r] = l_head; }
-  __syncthreads();                                // also: every wave is done with its staging strip
-  float m_all = fmaxf(fmaxf(mw[r], mw[16 + r]), fmaxf(mw[32 + r], mw[48 + r]));
-  float l_all = 0.f;
+  const long unit = (long)row * XS_SPLIT + sp;
+  if (r < H) {
+    float* dst = p.part_o + (unit * H + r) * D + wave * FW + g * 4;
 #pragma unroll
-  for (int w2 = 0; w2 < 4; w2++) l_all += lw[w2 * 16 + r] * __builtin_amdgcn_exp2f(mw[w2 * 16 + r] - m_all);
-  const float mine = __builtin_amdgcn_exp2f(m_ref - m_all) / l_all;
-  float* comb = (float*)xs_smem + r * G::CROW + g * 4;                        // [head][feature]
-  for (int w2 = 0; w2 < 4; w2++) {
-    if (wave == w2) {
-#pragma unroll
-      for (int mt = 0; mt < NMT; mt++) {
-        f32x4 v = acc[mt] * mine;
-        if (w2 > 0) v += *(const f32x4*)(comb + mt * 16);
-        *(f32x4*)(comb + mt * 16) = v;
-      }
-    }
-    __syncthreads();
+    for (int mt = 0; mt < NMT; mt++) *(f32x4*)(dst + mt * 16) = acc[mt];
   }
-  // normalised contexts -> xq (in place of this row's q'), 16-byte stores
-  {
-    bf16_t* out_row = p.xq + (long)row * H * D;
-    constexpr int CPR = D / 8;
-    const float* cb = (const float*)xs_smem;
-    for (int i = threadIdx.x; i < H * CPR; i += 256) {
-      const int hh = i / CPR, c = i - hh * CPR;
-      const float4 a = *(const float4*)(cb + hh * G::CROW + c * 8), b = *(const float4*)(cb + hh * G::CROW + c * 8 + 4);
-      *(bf16x8*)(out_row + (long)hh * D + c * 8) = pack8(a, b);
-    }
-  }
+  if (wave == 0 && g == 0) *(float2*)(p.part_ml + (unit * 16 + r) * 2) = make_float2(m_ref, l_head);
 }
 
 namespace {
@@ -260,11 +303,17 @@ namespace {
 template <int D>
 int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   using G = XsGeom<D>;
+  // p.lds_pad: dynamic LDS the streaming blocks claim without using it -- 64 KB leave ONE block per CU (which pulls the same ~25 GB/s
+  // as two), so that the chain kernels of the other decode lanes find wave slots and a shorter memory queue on every CU: 768-sequence
+  // decode step 6.25 -> 5.87 ms with two lanes.  CCX_XS_LDS_PAD overrides (experiments).
+  static const int forced_pad = [] { const char* e = getenv("CCX_XS_LDS_PAD"); return e ? atoi(e) : -1; }();
+  const int lds_pad = forced_pad >= 0 ? forced_pad : p.lds_pad;
   static bool attr_set = false;
   if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  CCX_REQUIRE(ctx, lds_pad >= 0 && G::LDS + lds_pad <= 160 * 1024, "xs cross attention: LDS claim %d too large", lds_pad);
   const dim3 small_grid(p.H, ccx_cdiv(p.rows, 16));
   const double wbytes = (double)p.H * 64 * D * 2;
   {
@@ -274,8 +323,8 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_CHECK_LAUNCH(ctx);
   {
     ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xs_stream_kernel<768>" : "dec_xs_stream_kernel", 4.0 * p.rows * 16 * (double)p.S * D,
-                      (double)p.rows * ((double)p.S * D * 2 + 2.0 * p.H * D * 2));
-    hipLaunchKernelGGL(dec_xs_stream_kernel<D>, dim3(p.rows), dim3(256), G::LDS, stream, p);
+                      (double)p.rows * ((double)p.S * D * 2 + p.H * D * 2.0 + XS_SPLIT * p.H * D * 4.0));
+    hipLaunchKernelGGL(dec_xs_stream_kernel<D>, dim3(p.rows * XS_SPLIT), dim3(256), G::LDS + lds_pad, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
   {
@@ -293,6 +342,7 @@ bool ccx_xs_supported(int D, int H) { return H >= 1 && H <= 16 && H * 64 == D &&
 int ccx_launch_xs_cross_attention(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, ccx_xs_supported(p.D, p.H), "xs cross attention: width %d with %d heads is not instantiated", p.D, p.H);
   CCX_REQUIRE(ctx, p.rows >= 1 && p.S >= 16 && p.q && p.WkT && p.xq && p.X && p.Wv && p.bv && p.out, "xs cross attention: bad arguments");
+  CCX_REQUIRE(ctx, p.part_o && p.part_ml, "xs cross attention: partial buffers missing");
   switch (p.D) {
     case 128: return launch_xs<128>(ctx, p, stream);
     case 256: return launch_xs<256>(ctx, p, stream);
@@ -335,12 +385,13 @@ extern "C" int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const fl
       for (int dd = 0; dd < 64; dd++) wkt[((size_t)hh * D + f) * 64 + dd] = xs_host_bf16(wk_host[(size_t)(hh * 64 + dd) * D + f]);
   for (size_t i = 0; i < wv.size(); i++) wv[i] = xs_host_bf16(wv_host[i]);
   bf16_t *d_wkt = nullptr, *d_wv = nullptr, *d_xq = nullptr, *d_out = nullptr;
-  float* d_bv = nullptr;
+  float *d_bv = nullptr, *d_po = nullptr, *d_pml = nullptr;
   int* d_rs = nullptr;
-  auto cleanup = [&]() { hipFree(d_wkt); hipFree(d_wv); hipFree(d_xq); hipFree(d_out); hipFree(d_bv); hipFree(d_rs); };
+  auto cleanup = [&]() { hipFree(d_wkt); hipFree(d_wv); hipFree(d_xq); hipFree(d_out); hipFree(d_bv); hipFree(d_rs); hipFree(d_po); hipFree(d_pml); };
 #define XS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return ccx_fail(ctx, CCX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
   XS_TRY(hipMalloc(&d_wkt, wkt.size() * 2)); XS_TRY(hipMalloc(&d_wv, wv.size() * 2)); XS_TRY(hipMalloc(&d_bv, (size_t)D * 4));
   XS_TRY(hipMalloc(&d_xq, (size_t)rows * H * D * 2)); XS_TRY(hipMalloc(&d_out, (size_t)rows * D * 2));
+  XS_TRY(hipMalloc(&d_po, ccx_xs_part_o_elems(rows, H, D) * 4)); XS_TRY(hipMalloc(&d_pml, ccx_xs_part_ml_elems(rows) * 4));
   XS_TRY(hipMemcpy(d_wkt, wkt.data(), wkt.size() * 2, hipMemcpyHostToDevice));
   XS_TRY(hipMemcpy(d_wv, wv.data(), wv.size() * 2, hipMemcpyHostToDevice));
   XS_TRY(hipMemcpy(d_bv, bv_host, (size_t)D * 4, hipMemcpyHostToDevice));
@@ -350,7 +401,7 @@ extern "C" int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const fl
   }
   XsParams p;
   memset(&p, 0, sizeof(p));
-  p.q = q_dev; p.WkT = d_wkt; p.xq = d_xq; p.X = xa_dev; p.x_seq_stride = (long)S * D; p.row_seq = d_rs; p.Wv = d_wv; p.bv = d_bv; p.out = d_out;
+  p.q = q_dev; p.WkT = d_wkt; p.xq = d_xq; p.X = xa_dev; p.x_seq_stride = (long)S * D; p.row_seq = d_rs; p.Wv = d_wv; p.bv = d_bv; p.out = d_out; p.part_o = d_po; p.part_ml = d_pml;
   p.rows = rows; p.H = H; p.S = S; p.D = D; p.scale_log2e = 0.125f * 1.4426950408889634f;
   int rc = ccx_launch_xs_cross_attention(ctx, p, stream);
   if (rc == CCX_OK) {

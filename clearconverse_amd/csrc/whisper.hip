@@ -140,7 +140,8 @@ struct ccx_whisper {
   // of <= 16 sequences (kv_ready = sequences valid since the last encode).
   bool xs_on = false, xs_active = false;
   int kv_cap = 0, kv_ready = 0;
-  bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries / contexts [rows][H][D] (step rows, prefill rows)
+  bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
+  float *xs_po = nullptr, *xs_pml = nullptr, *pf_xs_po = nullptr, *pf_xs_pml = nullptr;   // key-half partials (cross_x.h)
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
                                              // queue run strictly one after the other, so lanes are picked by a probe
@@ -582,6 +583,10 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   if (w->xs_on) {
     TRY(dev_alloc(w, &w->xq, (size_t)B * H * D, true));
     TRY(dev_alloc(w, &w->pf_xq, (size_t)B * ccx_whisper::kPrefillMax * H * D, true));
+    TRY(dev_alloc(w, &w->xs_po, ccx_xs_part_o_elems(B, H, D), true));
+    TRY(dev_alloc(w, &w->xs_pml, ccx_xs_part_ml_elems(B), true));
+    TRY(dev_alloc(w, &w->pf_xs_po, ccx_xs_part_o_elems((size_t)B * ccx_whisper::kPrefillMax, H, D), true));
+    TRY(dev_alloc(w, &w->pf_xs_pml, ccx_xs_part_ml_elems((size_t)B * ccx_whisper::kPrefillMax), true));
   }
   TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dx2, (size_t)B * D, true));
@@ -1027,9 +1032,12 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
         XsParams xp;
         memset(&xp, 0, sizeof(xp));
         xp.q = dq; xp.WkT = L.WckT; xp.xq = pre ? w->pf_xq : w->xq + ro * H * D;
+        xp.part_o = pre ? w->pf_xs_po : w->xs_po + ccx_xs_part_o_elems(ro, H, D);
+        xp.part_ml = pre ? w->pf_xs_pml : w->xs_pml + ccx_xs_part_ml_elems(ro);
         xp.X = pre ? w->xa : w->xa + ro * (long)d.n_audio_ctx * D; xp.x_seq_stride = (long)d.n_audio_ctx * D; xp.row_seq = row_seq;
         xp.Wv = L.Wckv + (long)D * D; xp.bv = L.bckv + D; xp.out = dattn;
         xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
+        xp.lds_pad = (w->cross_lds_pad > 0 && !pre) ? 65536 : 0;
         TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
       }
       stamp(2, 1);
@@ -1248,7 +1256,9 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     if (forced >= 1) nl = forced;
     // measured at 192 sequences x 65 steps: 1 lane 292.5, 2 286.8, 3 284.9, 4 284.8 ms; pipeline step with 384-sequence groups: 2 lanes
     // 710.0, 3 lanes 698.0 ms; with 768-sequence groups: 1 lane 721.5, 2 lanes 676.6, 3 lanes 687.5, 4 lanes 704.0 ms
-    else nl = B >= 640 ? 2 : (B >= 144 ? 3 : (B >= 96 ? 2 : 1));
+    // with the cross attention against the encoder output (half the bytes: the chain weighs more): 768-sequence groups 2 lanes 561.3,
+    // 3 lanes 557.9 ms per pipeline step
+    else nl = B >= 640 ? (w->xs_on ? 3 : 2) : (B >= 144 ? 3 : (B >= 96 ? 2 : 1));
     if (nl > ccx_whisper::kMaxLanes) nl = ccx_whisper::kMaxLanes;
     while (nl > 1 && B / nl < 16) nl--;
   }
