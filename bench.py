@@ -50,9 +50,10 @@ def enc_flops_per_window(d):
 def cross_bytes_per_sequence(d, xstream=True):
     """Algorithmic HBM bytes of ONE layer's cross attention for ONE sequence and decode step.  The reference's formulation reads the
     layer's K and V (2 x n_audio_ctx x D bf16); the X-stream formulation reads the encoder output once
-    (n_audio_ctx x D bf16) plus the expanded queries in and the contexts out (2 x heads x D bf16)."""
+    (n_audio_ctx x D bf16) plus the expanded queries (heads x D bf16) and writes the two key halves' partial contexts (2 x heads x D f32)
+    -- the bytes of dec_xs_stream_kernel, the dominant launch (csrc/cross_x.hip)."""
     D, S, H = d.n_text_state, d.n_audio_ctx, d.n_text_head
-    return S * D * 2 + 2 * H * D * 2 if xstream else 2 * S * D * 2
+    return S * D * 2 + H * D * 2 + 2 * H * D * 4 if xstream else 2 * S * D * 2
 
 
 def decode_bytes_per_step(d, B, xstream=True):

@@ -144,7 +144,7 @@ struct XsGeom {
   static constexpr int FW = D / 4;             // features per wave
   static constexpr int NKS = FW / 32;          // k-steps of a wave's partial scores
   static constexpr int NMT = FW / 16;          // M tiles of a wave's context slice
-  static constexpr int PF = 4;                 // key tiles a wave keeps in flight
+  static constexpr int PF = 4;                 // key tiles a wave keeps in flight (in situ, 768 sequences in 3 lanes: 2 -> 5.92, 3 -> 5.70, 4 -> 5.65, 6 -> 6.0 ms per step)
   static constexpr int RS = 2 * FW + 32;       // bytes per staged key row: +32 makes the transposed reads of 8 rows hit 64 different banks
   static constexpr int STRIP = 16 * RS;        // one wave's staging strip (private: no barrier)
   static constexpr int S_OFF = 4 * STRIP;      // partial-score exchange: [2 buffers][4 waves][64 lanes] f32x4

@@ -3,7 +3,10 @@ FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of wide coalesced 
 rocprofv3 section); WRITE_SIZE is exact; both are in KB."""
 import csv, json, sys, collections
 
-GRID = {}      # kernel -> set of Grid_Size values seen (the decode cross attention: sequences per launch = grid / 256 / heads)
+GRID = {}      # kernel -> set of Grid_Size values seen
+# the decode cross attention: sequences per launch = grid / 256 / blocks per sequence (12 heads for the K/V-cache kernel, 2 key halves
+# for the kernel that streams the encoder output)
+STREAMERS = ("dec_cross_stream_kernel", "dec_xs_stream_kernel")
 
 
 def load(path, counter):
@@ -18,10 +21,10 @@ def load(path, counter):
                 name = name.replace(pre, "")
             name = name.split("(")[0].replace(", ", ",")      # "dec_cross_stream_kernel<true,12,false>": the label bench.py uses
             g = r.get("Grid_Size") or r.get("Grid_Size_X")
-            if name.startswith("dec_cross_stream_kernel") and g:
+            if name.startswith(STREAMERS) and g:
                 # one entry per launch shape (bench.py's probe decodes a slightly smaller group than the timed region): the shape with
                 # the most launches becomes the kernel's entry below, the others stay beside it as "<name> @<sequences>"
-                name = f"{name} @{int(g) // 256 // 12}"
+                name = f"{name} @{int(g) // 256 // (2 if name.startswith('dec_xs_stream_kernel') else 12)}"
             key = (r["Dispatch_Id"], name)
             a = per[name]
             if key not in seen:
@@ -60,10 +63,10 @@ for name, (n, fk, wk) in base.items():
         out[name] = {"launches": n, "FETCH_SIZE_kb_per_launch": fk / n, "WRITE_SIZE_kb_per_launch": wk / n,
                      "hbm_bytes_per_launch": (2.0 * fk + wk) / n * 1024.0, "note": note + "; all template instantiations together"}
 # Counter collection serialises dispatches, so the decode-lane stream probe finds no concurrent stream and a decode group runs in
-# ONE lane: the sequences a cross-attention launch covers are read off its grid (one 256-thread block per (sequence, head), 12 heads).
+# ONE lane: the sequences a cross-attention launch covers are read off its grid.
 shapes = collections.defaultdict(list)
 for name in list(out):
-    if name.startswith("dec_cross_stream_kernel") and " @" in name:
+    if name.startswith(STREAMERS) and " @" in name:
         base_name, seqs = name.split(" @")
         out[name]["sequences_per_launch"] = int(seqs)
         shapes[base_name].append((out[name]["launches"], int(seqs), name))
