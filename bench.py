@@ -411,9 +411,11 @@ def main():
     wm = models["whisper_model"] if pipeline else model
     span = args.decode_span if (pipeline and args.schedule == "pipelined") else 1
     Bd = min(args.whisper_group, 6 * B * span) if pipeline else B
-    # The probe decodes a group that is 16 rows per lane SMALLER than the timed one (768 -> 736 sequences = 2 lanes of 368): the same
-    # kernels and lane count, but a launch shape of its own, so that rocprofv3's per-grid summary of this command
-    # (tools/kernel_trace_by_grid.py, profiles/) shows exactly these launches in a row of their own next to `roofline.avg_launch_us`.
+    # Two probes.  (1) a group 16 rows per lane SMALLER than the timed one (768 -> 720 sequences = 3 lanes of 240): the same kernels and
+    # lane count but a launch shape of its own, so that rocprofv3's per-grid summary of this command (tools/kernel_trace_by_grid.py,
+    # profiles/) shows exactly these launches in a row of their own next to `roofline.probe_distinct_grid.avg_launch_us`.  (2) the timed
+    # region's own group size: `roofline.achieved` is measured AT the launch shape the timed region runs (a cross-attention launch takes
+    # as long as the CU with the most blocks: 240 rows = 480 blocks leave the chip unevenly loaded, 256 rows = 512 blocks do not).
     def n_lanes(b):                       # as ccx_whisper_decode cuts a group into lanes
         return (3 if xstream else 2) if b >= 640 else (3 if b >= 144 else (2 if b >= 96 else 1))
     nl_real = n_lanes(Bd)
@@ -421,8 +423,15 @@ def main():
     if n_lanes(Bp) != nl_real or nl_real == 1:
         Bp = Bd
     os.environ["CCX_NO_GRAPH"] = "1"
+    probe_x = None
+    if Bp != Bd:
+        ctx.prof_enable(True)
+        wm.decode_greedy([[rules.sot]] * Bp, sample_len=probe_steps)
+        torch.cuda.synchronize()
+        probe_x = ctx.prof_records()
+        ctx.prof_enable(False)
     ctx.prof_enable(True)
-    wm.decode_greedy([[rules.sot]] * Bp, sample_len=probe_steps)
+    wm.decode_greedy([[rules.sot]] * Bd, sample_len=probe_steps)
     torch.cuda.synchronize()
     probe = ctx.prof_records()
     ctx.prof_enable(False)
@@ -518,9 +527,9 @@ def main():
             if k.startswith("dec_") and (v[1] > 0 or v[2] > 0):
                 launches = v[0] / (probe_steps) * decode_steps_per_step
                 # (scaled from the probe's lane size to the timed group's: these kernels' time is proportional to the rows they stream)
-                per_step[k] = (v[3] / v[0] * launches * (Bd / Bp),
-                               f"HIP events on the lanes' streams, eager re-run of {probe_steps} decode steps of a {Bp}-sequence group on the "
-                               f"encoded batch ({nl_real} lane(s); graph-resident in the timed region, where the group has {Bd} sequences)")
+                per_step[k] = (v[3] / v[0] * launches,
+                               f"HIP events on the lanes' streams, eager re-run of {probe_steps} decode steps of the {Bd}-sequence group of the "
+                               f"timed region on the encoded batch ({nl_real} lane(s); graph-resident in the timed region)")
         roof = roof_mfma = None
         if per_step:
             name = max(per_step, key=lambda k: per_step[k][0])
@@ -528,6 +537,13 @@ def main():
             cnt_, fl, by, ms = src[name]
             roof = roof_entry(name, cnt_, fl, by, ms, per_step[name][1])
             roof["ms_per_step"] = round(per_step[name][0], 2)
+            if probe_x is not None and name.startswith("dec_"):
+                xr = [(fl_, by_, ms_) for n_, fl_, by_, ms_ in probe_x if n_ == name]
+                if xr:
+                    roof["probe_distinct_grid"] = dict(sequences=Bp, launches=len(xr), avg_launch_us=round(sum(r_[2] for r_ in xr) * 1e3 / len(xr), 2),
+                                                       bytes_per_launch=sum(r_[1] for r_ in xr) / len(xr),
+                                                       what=f"the same eager probe on a {Bp}-sequence group: a grid no other launch of this process has "
+                                                            "(the row to look for in profiles/*_default_kernel_stats_by_grid.csv)")
             if name.startswith(("dec_cross_stream_kernel", "dec_xs_stream_kernel")) and in_situ:
                 # the same kernel inside the replayed step graphs with every lane of the group running: bytes of a lane's launch /
                 # median stamp-to-stamp time, averaged over the lanes
