@@ -994,6 +994,18 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   static const int ablate = [] { const char* e = getenv("CCX_ABLATE"); return !e ? 0 : (!strcmp(e, "cross") ? 1 : (!strcmp(e, "chain") ? 2 : 0)); }();
   for (int l = 0; l < d.n_text_layer; l++) {
     const DecLayer& L = w->dec[l];
+    if (ablate == 2 && w->xs_active) {
+      XsParams xp;
+      memset(&xp, 0, sizeof(xp));
+      xp.q = dq; xp.WkT = L.WckT; xp.xq = w->xq + ro * H * D;
+      xp.part_o = w->xs_po + ccx_xs_part_o_elems(ro, H, D); xp.part_ml = w->xs_pml + ccx_xs_part_ml_elems(ro);
+      xp.X = w->xa + ro * (long)d.n_audio_ctx * D; xp.x_seq_stride = (long)d.n_audio_ctx * D;
+      xp.Wv = L.Wckv + (long)D * D; xp.bv = L.bckv + D; xp.out = dattn;
+      xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
+      xp.lds_pad = w->cross_lds_pad > 0 ? 65536 : 0;
+      TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
+      continue;
+    }
     if (ablate == 2 && B > 16 && !w->xs_active) {
       DecAttnParams ap;
       memset(&ap, 0, sizeof(ap));
@@ -1311,7 +1323,8 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
   int step = prefill ? 1 : 0;                   // the prefill's own sample counts as step 0
   if (step < total_steps) {
     for (int i = 0; i < nl; i++) {
-      if (i > 0) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
+      static const bool stagger_on = [] { const char* e = getenv("CCX_LANE_STAGGER"); return !e || atoi(e) != 0; }();
+      if (i > 0 && stagger_on) CCX_HIP(ctx, hipStreamWaitEvent(lanes[i].s, w->lane_start[i - 1], 0));
       TRY(step_lane(i, (i + 1 < nl) ? w->lane_start[i] : nullptr));
       if (ctx->prof_on && !use_graph && nl > 1) CCX_HIP(ctx, hipStreamSynchronize(lanes[i].s));
     }
