@@ -12,7 +12,13 @@
 // The price is 12 x the matrix work (every head against all 768 features instead of its 64), which goes to the matrix cores:
 // heads are the N index of the MFMAs.
 struct XsParams {
-  const float* q;        // [rows][D] f32 queries (bias included, not scaled)
+  const float* q;        // [rows][D] f32 queries (bias included, not scaled) -- used when x is null
+  // query projection inside the expansion (dec_xq_fused_kernel): q = LN(x + pending slabs) Wq^T + bq computed per (head, 16 rows) block
+  const float* x; const float* pend; int pend_n; long pend_stride;   // residual rows [rows][D] and split-K partial slabs (decoder.h)
+  float* x_out;          // if non-null: the resolved residual rows are written here (must differ from x)
+  const float* ln_g; const float* ln_b; float eps;
+  const bf16_t* Wq;      // [D][D] row-major cross_attn.query.weight
+  const float* bq;       // [D]
   const bf16_t* WkT;     // [H][D][64]: WkT[h][f][d] = Wk[h*64 + d][f]   (cross_attn.key.weight re-laid per head)
   bf16_t* xq;            // [rows][H][D]: expanded queries
   float* part_o;         // [rows][XS_SPLIT][H][D]: unnormalised contexts of each key half (ccx_xs_part_o_elems)

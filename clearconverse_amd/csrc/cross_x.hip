@@ -7,6 +7,7 @@
 //   dec_xv_project_kernel  out[row][h*64 .. +64] = ctx[row][h] Wv_h^T + bv                 (D -> 64 per head)
 // (the kernels carry their own descriptions)
 #include "cross_x.h"
+#include "dec_ln.h"
 
 namespace {
 
@@ -48,6 +49,117 @@ __global__ __launch_bounds__(256) void dec_xq_expand_kernel(XsParams p) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qb[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qb[1], c, 0, 0, 0);
     if (live) *(u32x2*)(dst + mt * 16) = (u32x2){pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3])};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same expansion WITH the query projection and its LayerNorm inside: one launch instead of three (resolve + LayerNorm, the
+// skinny linear Wq, the expansion) on a chain that is latency-bound launch by launch.  Block = (head, 16 rows):
+//   A. every wave resolves and normalises four of the 16 residual rows (x + pending split-K slabs; the shared ln_* pieces of
+//      decoder.hip) into LDS as bf16 -- the 12 heads' blocks redo this for the same rows (L2 traffic, no launch); the blocks of
+//      head 0 also write the resolved rows to x_out (the residual stream's ping-pong buffer).  The head's 64 x D slice of Wq is
+//      requested before, so it flies under the LayerNorm;
+//   B. q^T [64 d x 16 rows] = Wq_h LN(x)^T + bq: wave w owns d = 16 w .. 16 w + 15 (D/32 MFMAs), result to LDS as bf16;
+//   C. the expansion as in dec_xq_expand_kernel, its B operand out of LDS.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xs_wave_sum(float v) { return wave_reduce_sum(v); }
+
+template <int D>
+__global__ __launch_bounds__(256) void dec_xq_fused_kernel(XsParams p) {
+  constexpr int NKS = D / 32, FW = D / 4, NMT = FW / 16, RSX = 2 * D + 16, RSQ = 2 * 64 + 16, NV = D / 4, NI = (NV + 63) / 64;
+  __shared__ __attribute__((aligned(16))) char xn_s[16 * RSX];
+  __shared__ __attribute__((aligned(16))) char q_s[16 * RSQ];
+  const int h = blockIdx.x, r0 = blockIdx.y * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  // the head's slice of Wq: wave w -> rows h*64 + 16 w + n
+  bf16x8 wq[NKS];
+  {
+    const bf16_t* wsrc = p.Wq + (long)(h * 64 + wave * 16 + n) * D + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) wq[ks] = *(const bf16x8*)(wsrc + ks * 32);
+  }
+  // A. resolve + LayerNorm of rows 4 wave .. 4 wave + 3
+  {
+    float4 gg[NI], bb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int idx = lane + 64 * i, ic = idx < NV ? idx : 0;
+      gg[i] = ((const float4*)p.ln_g)[ic];
+      bb[i] = ((const float4*)p.ln_b)[ic];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int lr = wave * 4 + rr;
+      int m = r0 + lr;
+      const bool live = m < p.rows;
+      if (!live) m = p.rows - 1;
+      float4 v[NI];
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const int idx = lane + 64 * i, ic = idx < NV ? idx : 0;
+        float4 a = ((const float4*)(p.x + (long)m * D))[ic];
+        float4 q[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) q[s2] = ((const float4*)(p.pend + (long)(s2 < p.pend_n ? s2 : 0) * p.pend_stride + (long)m * D))[ic];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) a = ln_add_pend(a, s2 < p.pend_n ? 1.f : 0.f, q[s2]);
+        if (idx >= NV) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = a;
+        if (p.x_out && h == 0 && live && idx < NV) ((float4*)(p.x_out + (long)m * D))[idx] = a;
+        sm += ln_sum4(a);
+      }
+      const float mean = xs_wave_sum(sm) / (float)D;
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const float t = ln_sq4(v[i], mean);
+        sq += (lane + 64 * i < NV) ? t : 0.f;
+      }
+      const float rstd = rsqrtf(xs_wave_sum(sq) / (float)D + p.eps);
+#pragma unroll
+      for (int i = 0; i < NI; i++) {
+        const int idx = lane + 64 * i;
+        if (idx < NV) *(uint2*)(xn_s + lr * RSX + idx * 8) = ln_pack4(v[i], mean, rstd, gg[i], bb[i]);
+      }
+    }
+  }
+  __syncthreads();
+  // B. q^T tile of this wave
+  f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+  {
+    const char* xsrc = xn_s + n * RSX + g * 16;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) {
+      const bf16x8 b = *(const bf16x8*)(xsrc + ks * 64);
+      if (ks & 1) cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks], b, cb, 0, 0, 0);
+      else ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks], b, ca, 0, 0, 0);
+    }
+  }
+  // the expansion's weights fly under the LDS round trip of q
+  const bf16_t* wbase = p.WkT + ((long)h * D + wave * FW + n) * 64 + g * 8;
+  bf16x8 wk[NMT][2];
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    wk[mt][0] = *(const bf16x8*)(wbase + (long)mt * 16 * 64);
+    wk[mt][1] = *(const bf16x8*)(wbase + (long)mt * 16 * 64 + 32);
+  }
+  {
+    const float4 bias = *(const float4*)(p.bq + h * 64 + wave * 16 + g * 4);
+    const float v0 = ca[0] + cb[0] + bias.x, v1 = ca[1] + cb[1] + bias.y, v2 = ca[2] + cb[2] + bias.z, v3 = ca[3] + cb[3] + bias.w;
+    *(u32x2*)(q_s + n * RSQ + (wave * 16 + g * 4) * 2) = (u32x2){pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+  }
+  __syncthreads();
+  // C. expansion
+  const bf16x8 qb0 = *(const bf16x8*)(q_s + n * RSQ + g * 16), qb1 = *(const bf16x8*)(q_s + n * RSQ + 64 + g * 16);
+  const int row = r0 + n;
+  bf16_t* dst = p.xq + ((long)(row < p.rows ? row : p.rows - 1) * p.H + h) * D + wave * FW + g * 4;
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk[mt][0], qb0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk[mt][1], qb1, c, 0, 0, 0);
+    if (row < p.rows) *(u32x2*)(dst + mt * 16) = (u32x2){pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3])};
   }
 }
 
@@ -316,7 +428,11 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, lds_pad >= 0 && G::LDS + lds_pad <= 160 * 1024, "xs cross attention: LDS claim %d too large", lds_pad);
   const dim3 small_grid(p.H, ccx_cdiv(p.rows, 16));
   const double wbytes = (double)p.H * 64 * D * 2;
-  {
+  if (p.x) {
+    ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xq_fused_kernel<768>" : "dec_xq_fused_kernel", 2.0 * p.rows * D * (double)D * 2,
+                      2.0 * wbytes + (double)p.rows * D * 4 * (1 + p.pend_n) + (double)p.rows * p.H * D * 2);
+    hipLaunchKernelGGL(dec_xq_fused_kernel<D>, small_grid, dim3(256), 0, stream, p);
+  } else {
     ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xq_expand_kernel<768>" : "dec_xq_expand_kernel", 2.0 * p.rows * p.H * 64 * D, wbytes + (double)p.rows * D * 4 + (double)p.rows * p.H * D * 2);
     hipLaunchKernelGGL(dec_xq_expand_kernel<D>, small_grid, dim3(256), 0, stream, p);
   }
@@ -341,7 +457,8 @@ bool ccx_xs_supported(int D, int H) { return H >= 1 && H <= 16 && H * 64 == D &&
 
 int ccx_launch_xs_cross_attention(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, ccx_xs_supported(p.D, p.H), "xs cross attention: width %d with %d heads is not instantiated", p.D, p.H);
-  CCX_REQUIRE(ctx, p.rows >= 1 && p.S >= 16 && p.q && p.WkT && p.xq && p.X && p.Wv && p.bv && p.out, "xs cross attention: bad arguments");
+  CCX_REQUIRE(ctx, p.rows >= 1 && p.S >= 16 && (p.q || p.x) && p.WkT && p.xq && p.X && p.Wv && p.bv && p.out, "xs cross attention: bad arguments");
+  CCX_REQUIRE(ctx, !p.x || (p.pend && p.ln_g && p.ln_b && p.Wq && p.bq && p.pend_n >= 0 && p.pend_n <= 4 && p.x_out != p.x), "xs cross attention: bad fused-query arguments");
   CCX_REQUIRE(ctx, p.part_o && p.part_ml, "xs cross attention: partial buffers missing");
   switch (p.D) {
     case 128: return launch_xs<128>(ctx, p, stream);

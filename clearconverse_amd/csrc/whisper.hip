@@ -60,6 +60,7 @@ struct DecLayer {
   bf16_t *Wqkv, *Wo, *Wcq, *Wckv, *Wco, *W1, *W2;
   bf16_t* W1_plain = nullptr;   // fc1 once more in plain row-major [F][D] for the tiled GEMM (lanes of >= 256 rows, prefill)
   bf16_t* WckT = nullptr;       // cross_attn.key.weight re-laid per head [H][D][64] for the expanded query (cross_x.hip)
+  bf16_t* Wcq_plain = nullptr;  // cross_attn.query.weight in plain row-major [D][D] (dec_xq_fused_kernel)
   float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
   bf16_t *crossK, *crossV, *selfK, *selfV;
 };
@@ -547,6 +548,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
         for (int f = 0; f < D; f++)
           for (int dd = 0; dd < 64; dd++) wkt[((size_t)hh * D + f) * 64 + dd] = ckw->data[(size_t)(hh * 64 + dd) * D + f];
       TRY(up_bf16(w, &L.WckT, wkt.data(), wkt.size()));
+      TRY(up_bf16(w, &L.Wcq_plain, cqw->data.data(), cqw->data.size()));
     }
     const size_t ck = (size_t)w->kv_cap * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
     TRY(dev_alloc(w, &L.crossK, ck, true)); TRY(dev_alloc(w, &L.crossV, ck, true));
@@ -1035,7 +1037,11 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     // LN(x) Wcq^T runs INSIDE the cross-attention blocks (ccx_launch_dec_cross_fused_q: one launch fewer per layer on a chain that
     // is latency-bound launch by launch; q is bit-identical to the two-launch path).  CCX_FUSE_CROSS_Q=0 restores the two launches.
     const bool fuse_q = w->fuse_cross_q && !pre && B <= 16 && D == 768 && ablate == 0 && !w->xs_active;
-    if (!fuse_q) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
+    // X-stream path: the query projection (with its resolve + LayerNorm) runs inside the expansion kernel -- one launch for three
+    // (CCX_XS_FUSE_Q=0: the three launches)
+    static const bool xs_fuse_q = [] { const char* e = getenv("CCX_XS_FUSE_Q"); return !e || atoi(e) != 0; }();
+    const bool xs_fused = w->xs_active && xs_fuse_q;
+    if (!fuse_q && !xs_fused) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     if (w->xs_active) {
@@ -1043,6 +1049,10 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       if (ablate != 1) {
         XsParams xp;
         memset(&xp, 0, sizeof(xp));
+        if (xs_fused) {
+          xp.x = cur; xp.pend = pend; xp.pend_n = pend_n; xp.pend_stride = pstride; xp.x_out = pend_n > 0 ? other : nullptr;
+          xp.ln_g = L.lnc_g; xp.ln_b = L.lnc_b; xp.eps = 1e-5f; xp.Wq = L.Wcq_plain; xp.bq = L.bcq;
+        }
         xp.q = dq; xp.WkT = L.WckT; xp.xq = pre ? w->pf_xq : w->xq + ro * H * D;
         xp.part_o = pre ? w->pf_xs_po : w->xs_po + ccx_xs_part_o_elems(ro, H, D);
         xp.part_ml = pre ? w->pf_xs_pml : w->xs_pml + ccx_xs_part_ml_elems(ro);
@@ -1051,6 +1061,9 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
         xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
         xp.lds_pad = (w->cross_lds_pad > 0 && !pre) ? 65536 : 0;
         TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
+        if (xs_fused && pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
+      } else if (xs_fused) {
+        TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));     // chain-only ablation: keep the resolve
       }
       stamp(2, 1);
       TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
