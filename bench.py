@@ -566,7 +566,10 @@ def main():
                                                             "linears, logits, select), lanes concurrent, graph replay")
                 roof["in_situ"] = dict(lanes=[{k: (round(v, 1) if isinstance(v, float) else v) for k, v in l.items()} for l in in_situ],
                                        measured="in-graph s_memrealtime stamps around every layer's cross attention (ccx_whisper_trace_lanes), "
-                                                f"graph replay of a {Bd}-sequence group, all lanes concurrent; includes the ~2 us stamp nodes")
+                                                f"graph replay of a {Bd}-sequence group, all lanes concurrent; includes the ~2 us stamp nodes"
+                                                + ("; with the cross attention against the encoder output the stamps bracket its THREE launches (LayerNorm + "
+                                                   "query projection + expansion, the streaming kernel, merge + value projection: 17 + 110 + 8 us alone), and "
+                                                   "`achieved_in_situ` divides the streaming kernel's bytes by the whole bracket" if xstream else ""))
         if "gemm_bf16_nt_kernel" in agg and (roof is None or roof["kernel"] != "gemm_bf16_nt_kernel"):
             cnt_, fl, by, ms = agg["gemm_bf16_nt_kernel"]
             roof_mfma = roof_entry("gemm_bf16_nt_kernel", cnt_, fl, by, ms, where_eager)
