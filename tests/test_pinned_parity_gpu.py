@@ -39,11 +39,13 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("size", ["mini", "full"])
-def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx, size):
+@pytest.mark.parametrize("size", ["mini", "full", "full-xstream"])
+def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx, size, monkeypatch):
     """size "mini": 2-layer / 128-wide Whisper and a 2-layer SepFormer, two clips.  size "full": the BASELINE architectures (small.en:
     12 + 12 layers of 768; RE-SepFormer at full depth: 8 layers x 3 blocks), one clip, 3 decoded tokens per Whisper call -- the whole
-    pinned pipeline against the CPU oracle pipeline at the sizes the bench runs (the oracle needs about a minute for it)."""
+    pinned pipeline against the CPU oracle pipeline at the sizes the bench runs (the oracle needs about a minute for it).  A clip is 6
+    Whisper windows, which decode on the K / V path; "full-xstream" puts them on the path the bench's 768-sequence groups take (the
+    cross attention against the encoder output, csrc/cross_x.hip: CCX_CROSS_X_MIN_ROWS=1), prompt prefill included."""
     from clearconverse_amd.batch import BatchPipeline
     from clearconverse_amd.models import build_state_dicts, load_models
     from clearconverse_amd.tokenizer import DecodeRules
@@ -51,7 +53,9 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx, size):
     from tests import pinned_oracle as O
 
     from tests.scripted_nets import scripted_pyannet_state_dict
-    full_size = size == "full"
+    full_size = size.startswith("full")
+    if size == "full-xstream":
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
     wd, sdims = (WhisperDims.small_en(), SepDims()) if full_size else (WhisperDims.mini(2, 128), SepDims(n_layers=2))
     sds = build_state_dicts(None, whisper_dims=wd, sep_dims=sdims, seed=7)
     # scripted segmentation weights (fitted to clip 40's schedule; clip 41 gets whatever they give on it): with seeded random
@@ -73,7 +77,8 @@ def test_run_pinned_matches_oracle_composed_pipeline(ccx_ctx, size):
 
     def track(name, v):
         worst[name] = max(worst.get(name, 0.0), float(v))
-        within(("run_pinned vs oracle pipeline (FULL small.en, full-depth SepFormer): " if full_size else
+        within(("run_pinned vs oracle pipeline (FULL small.en, X-stream decode): " if size == "full-xstream" else
+                "run_pinned vs oracle pipeline (FULL small.en, full-depth SepFormer): " if full_size else
                 "run_pinned vs oracle pipeline (mini Whisper, 2-layer SepFormer): ") + name, v, BOUNDS[name])
 
     for b, clip in enumerate(clips):
