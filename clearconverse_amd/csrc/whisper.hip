@@ -139,7 +139,7 @@ struct ccx_whisper {
   // (42 GB at 768 sequences), half the bytes per step.  xs_on: the instance was built for it (widths cross_x.hip instantiates,
   // CCX_CROSS_X != 0 at finalize); the K/V caches then hold kv_cap = 16 sequences and are filled from xa at the start of a decode
   // of <= 16 sequences (kv_ready = sequences valid since the last encode).
-  bool xs_on = false, xs_active = false;
+  bool xs_on = false, xs_active = false, xs_fuse_q = true;
   int kv_cap = 0, kv_ready = 0;
   bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
   float *xs_po = nullptr, *xs_pml = nullptr, *pf_xs_po = nullptr, *pf_xs_pml = nullptr;   // key-half partials (cross_x.h)
@@ -736,6 +736,7 @@ static int select_cross_path(ccx_whisper* w, int B, hipStream_t stream) {
   const char* e = getenv("CCX_CROSS_X_MIN_ROWS");
   const int min_rows = e ? atoi(e) : 17;
   w->xs_active = w->xs_on && B >= min_rows;
+  { const char* f = getenv("CCX_XS_FUSE_Q"); w->xs_fuse_q = !f || atoi(f) != 0; }      // read per call: tests flip it
   if (w->xs_on && !w->xs_active && w->kv_ready < B) TRY(project_cross_kv(w, B, stream));
   return CCX_OK;
 }
@@ -1039,8 +1040,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     const bool fuse_q = w->fuse_cross_q && !pre && B <= 16 && D == 768 && ablate == 0 && !w->xs_active;
     // X-stream path: the query projection (with its resolve + LayerNorm) runs inside the expansion kernel -- one launch for three
     // (CCX_XS_FUSE_Q=0: the three launches)
-    static const bool xs_fuse_q = [] { const char* e = getenv("CCX_XS_FUSE_Q"); return !e || atoi(e) != 0; }();
-    const bool xs_fused = w->xs_active && xs_fuse_q;
+    const bool xs_fused = w->xs_active && w->xs_fuse_q;
     if (!fuse_q && !xs_fused) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
@@ -1348,7 +1348,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8), i};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8) | ((w->xs_fuse_q ? 1 : 0) << 9), i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

@@ -400,6 +400,38 @@ def test_large_batch_decode_path_matches_small_batch(ccx_ctx, monkeypatch):
         m.close()
 
 
+def test_xstream_query_projection_inside_the_expansion_equals_three_launches(ccx_ctx, monkeypatch):
+    """X-stream path: resolve + LayerNorm, the query linear and the per-head expansion run as ONE kernel (dec_xq_fused_kernel) or, with
+    CCX_XS_FUSE_Q=0, as the three launches it replaces.  Same LayerNorm pieces, another summation order in the 768-long query dot
+    products: the same tokens and log-probabilities to 6e-5 relative (2.1e-5 measured), stepwise and prefilled, 40 sequences in lanes -- and both are
+    eps-argmax strings of the oracle."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        big = dev.repeat(10, 1).contiguous()
+        m.log_mel(big, n * 10); xa = m.encode(40, return_xa=True).cpu()
+        prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, 88, 99, rules.sot]] * 10
+        orc = _oracle(dims, sd)
+        for prefill in ("1", "0"):
+            monkeypatch.setenv("CCX_PREFILL", prefill)
+            monkeypatch.setenv("CCX_XS_FUSE_Q", "1")
+            one = m.decode_greedy(prompts, sample_len=12)
+            monkeypatch.setenv("CCX_XS_FUSE_Q", "0")
+            three = m.decode_greedy(prompts, sample_len=12)
+            for i in range(40):
+                assert one[i]["tokens"] == three[i]["tokens"], (prefill, i)
+                within("whisper mini X-stream: |sum_logprob fused query - three launches| / max(1, |.|)",
+                       abs(one[i]["sum_logprob"] - three[i]["sum_logprob"]) / max(1.0, abs(three[i]["sum_logprob"])), 6e-5, i)
+            for i in range(4):
+                _oracle_accepts(orc, xa[i:i + 1], prompts[i], one[i], 12, 0.05)
+    finally:
+        m.close()
+
+
 def test_lane_of_256_rows_and_more_matches_small_batch(ccx_ctx, monkeypatch):
     """Lanes of 128 rows and more (the 768-sequence decode groups of bench.py: 384 per lane) use 32-column blocks in the skinny
     linears -- another grid, the same sums: 264 sequences in ONE lane must decode exactly like a batch of 4."""
