@@ -2,9 +2,11 @@
 // reference call sites: back/api.py:1286-1292, 1432-1438, 1474-1480 -> openai-whisper MultiHeadAttention(x, xa) per decoder layer).
 //
 // Three launches per layer:
-//   dec_xq_expand_kernel   q'[row][h][:] = q[row][h*64 .. +64] Wk_h                        (64 -> D per head; 1.2 MB of weights)
-//   dec_xs_stream_kernel   ctx[row][h][:] = sum_j softmax_j(q'[row][h] . xa_j * scale) xa_j (ONE pass over the sequence's xa: the HBM-bound part)
-//   dec_xv_project_kernel  out[row][h*64 .. +64] = ctx[row][h] Wv_h^T + bv                 (D -> 64 per head)
+//   dec_xq_fused_kernel    q = LN(x + pending slabs) Wq^T + bq, then q'[row][h][:] = q[row][h*64 .. +64] Wk_h  (64 -> D per head)
+//                          (dec_xq_expand_kernel: the expansion alone, from a given q -- the C-ABI operator, CCX_XS_FUSE_Q=0)
+//   dec_xs_stream_kernel   partial contexts sum_j exp2(q'[row][h] . xa_j * scale - m) xa_j of a key half: ONE pass over the
+//                          sequence's xa for all heads -- the HBM-bound part
+//   dec_xv_project_kernel  merges the key halves, out[row][h*64 .. +64] = ctx[row][h] Wv_h^T + bv         (D -> 64 per head)
 // (the kernels carry their own descriptions)
 #include "cross_x.h"
 #include "dec_ln.h"
