@@ -99,3 +99,38 @@ def test_pmc_reduction_doubles_fetch_and_reads_sequences_off_the_grid(tmp_path):
     assert all_["dec_cross_stream_kernel<true,12,false> @336"]["hbm_bytes_per_launch"] == pytest.approx((2 * 756000.0 + 504.0) * 1024.0)
     assert d["hbm_bytes_per_launch"] == pytest.approx((2 * 864000.0 + 576.0) * 1024.0)        # FETCH_SIZE counts half of a wide read on gfx950
     assert d["note"].startswith("test note")
+
+
+def test_pmc_reduction_reads_the_rows_of_the_xstream_kernel_off_its_grid(tmp_path):
+    """dec_xs_stream_kernel runs TWO blocks per row (the key halves): 256 rows = grid 131072; the probe's 240 rows stay beside it."""
+    def write(path, counter, rows):
+        with open(path, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
+            for d, name, grid, val in rows:
+                w.writerow([d, name, grid, counter, val])
+    name = "void dec_xs_stream_kernel<768>(XsParams)"
+    write(tmp_path / "f.csv", "FETCH_SIZE", [(d, name, 256 * 2 * 256, 292000.0 / 8) for d in (1, 2, 3) for _ in range(8)]
+          + [(4, name, 240 * 2 * 256, 274000.0 / 8) for _ in range(8)])
+    write(tmp_path / "w.csv", "WRITE_SIZE", [(d, name, 256 * 2 * 256, 18400.0 / 8) for d in (1, 2, 3) for _ in range(8)]
+          + [(4, name, 240 * 2 * 256, 17250.0 / 8) for _ in range(8)])
+    out = tmp_path / "pmc.json"
+    subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_to_json.py"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), str(out), "test note"],
+                   check=True, capture_output=True)
+    all_ = json.loads(out.read_text())
+    d = all_["dec_xs_stream_kernel<768>"]
+    assert d["launches"] == 3 and d["sequences_per_launch"] == 256 and d["sequences_per_launch_seen"] == [240, 256]
+    assert d["hbm_bytes_per_launch"] == pytest.approx((2 * 292000.0 + 18400.0) * 1024.0)
+    assert all_["dec_xs_stream_kernel<768> @240"]["launches"] == 1
+
+
+def test_bench_prices_the_cross_attention_with_the_bytes_of_the_formulation_it_runs():
+    bench = importlib.import_module("bench")
+    from clearconverse_amd.weights import WhisperDims
+    d = WhisperDims.small_en()
+    assert bench.cross_bytes_per_sequence(d, xstream=False) == 2 * 1500 * 768 * 2                       # K and V of one layer (SURVEY 8d)
+    assert bench.cross_bytes_per_sequence(d, xstream=True) == 1500 * 768 * 2 + 12 * 768 * 2 + 2 * 12 * 768 * 4   # xa + q' + two partials
+    w = 2 * (12 * (4 * 768 * 768 + 2 * 768 * 3072 + 4 * 768 * 768) + 51864 * 768)
+    assert bench.decode_bytes_per_step(d, 768, True) == w + 768 * 12 * bench.cross_bytes_per_sequence(d, True)
+    enc, cross = bench.enc_flops_per_window(d)
+    assert round(enc / 1e9, 1) == 344.2 and round(cross / 1e9, 1) == 42.5
