@@ -142,7 +142,10 @@ int ccx_whisper_logmel(ccx_whisper* w, const float* audio_dev, int64_t stride, c
                        const int* seek_frames, int B, float* mel_out_dev, void* stream);
 /* Alternative input: take a ready [B, n_mels, 3000] f32 mel (BASELINE config 2 "mel [8,80,3000]"). */
 int ccx_whisper_set_mel(ccx_whisper* w, const float* mel_dev, int B, void* stream);
-/* AudioEncoder.forward for the B staged windows + per-layer cross-attention K/V projection.
+/* AudioEncoder.forward for the B staged windows.  The encoder output (bf16) stays with the instance: decodes of more than 16 sequences
+ * read it directly in their cross attention (csrc/cross_x.hip), decodes of <= 16 sequences project the per-layer cross-attention K / V
+ * of their sequences out of it when they start (with CCX_CROSS_X=0 at ccx_whisper_finalize this call projects K / V for all B, as in
+ * openai-whisper's kv_cache hooks).
  * xa_out_dev (optional): [B, n_audio_ctx, n_audio_state] f32 copy of the encoder output. */
 int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out_dev, void* stream);
 
