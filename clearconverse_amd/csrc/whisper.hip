@@ -602,7 +602,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   TRY(dev_alloc(w, &w->part_ml, (size_t)B * H * ccx_whisper::kCrossSplitMax * 2, true));
   TRY(dev_alloc(w, &w->cur_tok, (size_t)B, true));
   TRY(dev_alloc(w, &w->pos, (size_t)B, true));
-  TRY(dev_alloc(w, &w->n_done, (size_t)4, true));
+  TRY(dev_alloc(w, &w->n_done, (size_t)ccx_whisper::kMaxLanes, true));
   TRY(dev_alloc(w, &w->sample_cfg, (size_t)4, true));
   TRY(dev_alloc(w, &w->state, (size_t)B, true));
   {
@@ -1153,7 +1153,7 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
   CCX_HIP(w->ctx, hipMemcpyAsync(w->cur_tok, tok.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->pos, ps.data(), B * 4, hipMemcpyHostToDevice, stream));
   CCX_HIP(w->ctx, hipMemcpyAsync(w->prompt, prompt_ids, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, stream));
-  CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, 16, stream));
+  CCX_HIP(w->ctx, hipMemsetAsync(w->n_done, 0, ccx_whisper::kMaxLanes * 4, stream));
   w->sampling = temperature > 0.f;
   unsigned cfg[4] = {0u, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), 0u};
   memcpy(&cfg[0], &temperature, 4);
