@@ -1,7 +1,8 @@
 """GPU parity of the decode cross attention computed against the encoder output (csrc/cross_x.hip: expanded queries, ONE pass over
 xa for all heads, value projection afterwards) with a plain fp32 restatement of openai-whisper's MultiHeadAttention(x, xa) for one
 token: K = xa Wk^T, V = xa Wv^T + bv, softmax(q K^T / 8) V per head.  Through the C ABI (ccx_cross_attention_xa).
-Tolerance: rel-L2 <= 1e-2 per row (bf16 operands, fp32 accumulation), measured values in profiles/."""
+Tolerance: rel-L2 <= 1e-2 per row (bf16 operands, fp32 accumulation; worst measured 7.8e-3 at 2 heads, 5.0e-3 at 12),
+6e-3 where 2.7e-3 was measured; values in profiles/r03_measured_deviations.json."""
 import ctypes as C
 
 import numpy as np
@@ -88,7 +89,7 @@ def test_peaked_scores_and_the_repeat_pass(ccx_ctx):
         want = _reference(q, wk, wv, bv, xa, rs, H)
         assert torch.isfinite(got).all(), name
         for r in range(3):
-            within(f"cross attention against xa: peaked scores ({name}), rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), TOL, r)
+            within(f"cross attention against xa: peaked scores ({name}), rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), 6e-3, r)
 
 
 def test_rows_share_sequences_and_do_not_see_each_other(ccx_ctx):
@@ -99,7 +100,7 @@ def test_rows_share_sequences_and_do_not_see_each_other(ccx_ctx):
     got = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H)
     want = _reference(q, wk, wv, bv, xa, rs, H)
     for r in range(len(rs)):
-        within("cross attention against xa: rows mapped to sequences, rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), TOL, r)
+        within("cross attention against xa: rows mapped to sequences, rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), 6e-3, r)
     for r in (1, 3, 6):
         alone = _run(ccx_ctx, q[r:r + 1], wk, wv, bv, xa, [rs[r]], H)
         assert torch.equal(alone[0], got[r]), r

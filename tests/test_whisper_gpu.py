@@ -177,7 +177,7 @@ def _oracle_accepts(orc, xa_row, prompt, result, sample_len, tol):
         seq.append(t); sampled.append(t)
 
 
-def _two_paths_agree(name, orc, xa_row, prompt, ra, rb, sample_len, tol, bound=2e-3):
+def _two_paths_agree(name, orc, xa_row, prompt, ra, rb, sample_len, tol, bound=9e-4):
     """The same window decoded by the two cross-attention formulations (split-KV kernels on K / V caches for decodes of <= 16
     sequences, one pass over the encoder output for larger ones): equal tokens and log-probabilities to `bound` relative -- or,
     where a near-tie tips the other way, both token strings must be eps-argmax strings of the oracle.  Returns 1 for a divergence."""
