@@ -82,7 +82,7 @@ struct DecSelectParams {
 int ccx_launch_dec_select(ccx_ctx* ctx, const DecSelectParams& p, int B, hipStream_t stream);
 int ccx_launch_dec_embed(ccx_ctx* ctx, const float* tok_emb, const float* pos_emb, const int* cur_tok, const int* pos,
                          float* x, int B, int D, hipStream_t stream);
-// dst[i][:] = src[idx[i]][:] (bf16 rows of D elements): the last prompt row of every sequence after a prefill
+// dst[i][:] = src[idx[i]][:] where idx[i] >= 0 (bf16 rows of D elements): the last prompt row of every sequence after a prefill pass
 int ccx_launch_dec_gather_rows(ccx_ctx* ctx, const bf16_t* src, const int* idx, bf16_t* dst, int n, int D, hipStream_t stream);
 int ccx_launch_dec_combine(ccx_ctx* ctx, const float* part_o, const float* part_ml, int nsplit, bf16_t* out, int M, int H,
                            hipStream_t stream);

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restric
 }
 
 __global__ void dec_gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx, bf16_t* __restrict__ dst, int D) {
+  if (idx[blockIdx.x] < 0) return;                 // row not taken in this pass (chunked prefill): dst keeps what it has
   const uint4* s4 = (const uint4*)(src + (long)idx[blockIdx.x] * D);
   uint4* d4 = (uint4*)(dst + (long)blockIdx.x * D);
   for (int i = threadIdx.x; i < D / 8; i += blockDim.x) d4[i] = s4[i];

@@ -119,7 +119,7 @@ struct ccx_whisper {
   int max_prompt_cap = 0, sample_cap = 0;
   // prompt prefill: one pass over every prompt position of every sequence (rows = sequence * P + position) instead of one
   // decode step per prompt token; row-indexed copies of the step buffers and the row tables
-  static constexpr int kPrefillMax = 16;     // longest prompt (tokens) prefilled in one pass; longer ones are fed step by step
+  static constexpr int kPrefillMax = 16;     // prompt positions prefilled in one pass (longer prompts: several passes)
   float *pf_x = nullptr, *pf_x2 = nullptr, *pf_pend = nullptr, *pf_q = nullptr;
   bf16_t *pf_xn = nullptr, *pf_attn = nullptr, *pf_ffn = nullptr;
   int *pf_tok = nullptr, *pf_pos = nullptr, *pf_seq = nullptr, *pf_last = nullptr;
@@ -1165,30 +1165,38 @@ int upload_decode_state(ccx_whisper* w, const int32_t* prompt_ids, const int32_t
 }
 
 // Prompt prefill (openai-whisper's first forward over all initial tokens, decoding.py::_main_loop): every prompt position of every
-// sequence in ONE pass of the layer chain -- P = longest prompt, rows = sequence * P + position, positions past a shorter prompt
-// are dead rows (their K/V land beyond the prompt and are overwritten by the tokens decoded there later).  Leaves the self-KV
-// caches filled and the final-LayerNorm row of every sequence's last prompt position in w->dxn.
+// sequence through the layer chain in passes of up to kPrefillMax positions -- rows = sequence * Pc + (position - first position of
+// the pass); a pass sees the self-K/V of the earlier passes in the caches, so a long prompt (the reference feeds the previous
+// segment's transcript as `initial_prompt`, up to 223 tokens: back/api.py:1424-1426) costs one pass per 16 tokens instead of one
+// decode step per token.  Positions past a shorter prompt are dead rows (their K/V land beyond the prompt and are overwritten by the
+// tokens decoded there later).  Leaves the self-KV caches filled and the final-LayerNorm row of every sequence's last prompt
+// position in w->dxn.
 int run_prefill(ccx_whisper* w, const int32_t* prompt_ids, const int32_t* prompt_lens, int max_prompt, int B, int P, int sample_len,
                 hipStream_t stream) {
   ccx_ctx* ctx = w->ctx;
-  const int R = B * P, D = w->d.n_text_state;
-  std::vector<int> tok(R), ps(R), sq(R), last(B);
-  for (int b = 0; b < B; b++) {
-    for (int t = 0; t < P; t++) {
-      const int r = b * P + t;
-      tok[r] = t < prompt_lens[b] ? prompt_ids[(size_t)b * max_prompt + t] : w->rules.eot;
-      ps[r] = t; sq[r] = b;
+  const int D = w->d.n_text_state, C = ccx_whisper::kPrefillMax;
+  for (int t0 = 0; t0 < P; t0 += C) {
+    const int Pc = P - t0 < C ? P - t0 : C, R = B * Pc;
+    std::vector<int> tok(R), ps(R), sq(R), last(B);
+    for (int b = 0; b < B; b++) {
+      for (int t = 0; t < Pc; t++) {
+        const int r = b * Pc + t, ta = t0 + t;
+        tok[r] = ta < prompt_lens[b] ? prompt_ids[(size_t)b * max_prompt + ta] : w->rules.eot;
+        ps[r] = ta; sq[r] = b;
+      }
+      const int tl = prompt_lens[b] - 1 - t0;        // the sequence's last prompt position, relative to this pass
+      last[b] = (tl >= 0 && tl < Pc) ? b * Pc + tl : -1;
     }
-    last[b] = b * P + prompt_lens[b] - 1;
+    CCX_HIP(ctx, hipMemcpyAsync(w->pf_tok, tok.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+    CCX_HIP(ctx, hipMemcpyAsync(w->pf_pos, ps.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+    CCX_HIP(ctx, hipMemcpyAsync(w->pf_seq, sq.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
+    CCX_HIP(ctx, hipMemcpyAsync(w->pf_last, last.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    TRY(ccx_launch_dec_embed(ctx, w->tok_emb_f32, w->dec_pos, w->pf_tok, w->pf_pos, w->pf_x, R, D, stream));
+    CCX_HIP(ctx, hipStreamSynchronize(stream));     // host tables go out of scope
+    TRY(dec_step(w, 0, B, nullptr, 0, false, sample_len, max_prompt, nullptr, stream, nullptr, 0, Pc));
+    TRY(ccx_launch_dec_gather_rows(ctx, w->pf_xn, w->pf_last, w->dxn, B, D, stream));
   }
-  CCX_HIP(ctx, hipMemcpyAsync(w->pf_tok, tok.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
-  CCX_HIP(ctx, hipMemcpyAsync(w->pf_pos, ps.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
-  CCX_HIP(ctx, hipMemcpyAsync(w->pf_seq, sq.data(), (size_t)R * 4, hipMemcpyHostToDevice, stream));
-  CCX_HIP(ctx, hipMemcpyAsync(w->pf_last, last.data(), (size_t)B * 4, hipMemcpyHostToDevice, stream));
-  TRY(ccx_launch_dec_embed(ctx, w->tok_emb_f32, w->dec_pos, w->pf_tok, w->pf_pos, w->pf_x, R, D, stream));
-  CCX_HIP(ctx, hipStreamSynchronize(stream));     // host tables go out of scope
-  TRY(dec_step(w, 0, B, nullptr, 0, false, sample_len, max_prompt, nullptr, stream, nullptr, 0, P));
-  return ccx_launch_dec_gather_rows(ctx, w->pf_xn, w->pf_last, w->dxn, B, D, stream);
+  return CCX_OK;
 }
 
 }  // namespace
@@ -1263,9 +1271,11 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     }
     if (prompt_lens[b] > max_pl) max_pl = prompt_lens[b];
   }
-  // prompts of 2 .. kPrefillMax tokens are prefilled in one pass (CCX_PREFILL=0: one decode step per prompt token, round 1's way)
+  // prompts of 2 tokens and more are prefilled, kPrefillMax positions per pass (CCX_PREFILL=0: one decode step per prompt token, round
+  // 1's way; CCX_PREFILL_MAX=n: prompts longer than n tokens stepwise -- 16 was round 2's limit)
   const int prefill_on = [] { const char* e = getenv("CCX_PREFILL"); return e ? atoi(e) : 1; }();     // read per call: tests flip it
-  const bool prefill = prefill_on && max_pl >= 2 && max_pl <= ccx_whisper::kPrefillMax;
+  const int prefill_max = [] { const char* e = getenv("CCX_PREFILL_MAX"); return e ? atoi(e) : 1 << 30; }();
+  const bool prefill = prefill_on && max_pl >= 2 && max_pl <= prefill_max;
   TRY(select_cross_path(w, B, stream));
   TRY(upload_decode_state(w, prompt_ids, prompt_lens, max_prompt, B, temperature, seed, stream, prefill));
   // steps still to run after the (eager) first one: the prefill already covers the prompt AND takes the first sample below

@@ -539,3 +539,41 @@ def test_prompt_prefill_equals_stepwise_prompt_feeding(ccx_ctx, monkeypatch):
         assert one[0]["tokens"] == a[1]["tokens"][:1]
     finally:
         m.close()
+
+
+def test_long_prompts_are_prefilled_in_passes_of_16_positions(ccx_ctx, monkeypatch):
+    """The reference feeds the previous segment's transcript as `initial_prompt` (back/api.py:1424-1426: up to 223 tokens after
+    transcribe()'s truncation).  Prompts longer than 16 tokens are prefilled in several passes of 16 positions, each seeing the
+    self-K/V of the earlier ones in the caches: ragged lengths 40 / 17 / 3 / 33 (passes of 16 + 16 + 8 rows, sequences ending in
+    different passes) must decode exactly like stepwise prompt feeding (CCX_PREFILL=0), on the K/V path (4 sequences) and on the
+    X-stream path (40 sequences in lanes), greedy and sampled -- and are checked against the oracle."""
+    from clearconverse_amd.whisper import WhisperModel
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        g = np.random.default_rng(9)
+        prompts = [[rules.sot_prev] + [int(x) for x in g.integers(1000, 40000, k)] + [rules.sot] for k in (38, 15, 1, 31)]
+        assert [len(p) for p in prompts] == [40, 17, 3, 33]
+        m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
+        orc = _oracle(dims, sd)
+        for B, reps in ((4, 1), (40, 10)):
+            if reps > 1:
+                big = dev.repeat(reps, 1).contiguous()
+                m.log_mel(big, n * reps); m.encode(B)
+            a = m.decode_greedy(prompts * reps, sample_len=8)
+            s1 = m.decode(prompts * reps, sample_len=6, temperature=0.7, seed=5)
+            monkeypatch.setenv("CCX_PREFILL", "0")
+            b = m.decode_greedy(prompts * reps, sample_len=8)
+            s0 = m.decode(prompts * reps, sample_len=6, temperature=0.7, seed=5)
+            monkeypatch.delenv("CCX_PREFILL")
+            for i in range(B):
+                assert a[i]["tokens"] == b[i]["tokens"], (B, i, a[i]["tokens"], b[i]["tokens"])
+                assert a[i]["sum_logprob"] == b[i]["sum_logprob"] and a[i]["no_speech_prob"] == b[i]["no_speech_prob"], (B, i)   # same kernels per row
+                assert s1[i]["tokens"] == s0[i]["tokens"], (B, i)
+            for i in range(4):
+                _oracle_accepts(orc, xa[i:i + 1], prompts[i], a[i], 8, 0.08)
+    finally:
+        m.close()
