@@ -26,6 +26,7 @@ struct XsParams {
   const bf16_t* X;       // [sequences][x_seq_stride]: encoder output rows [S][D] per sequence
   long x_seq_stride;     // elements between sequences
   const int* row_seq;    // row -> sequence (prompt prefill: several rows per sequence); null: identity
+  int rows_per_seq;      // > 1: rows s * rows_per_seq .. + rows_per_seq - 1 all belong to sequence row_seq[s * rows_per_seq] (prefill)
   const bf16_t* Wv;      // [D][D] row-major cross_attn.value.weight
   const float* bv;       // [D]
   bf16_t* out;           // [rows][D] attention output (input of cross_attn.out)

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void dec_xv_project_kernel(XsParams p) {
 // the streaming kernel
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
-template <int D>
+template <int D, int RB = 1>
 struct XsGeom {
   static constexpr int FW = D / 4;             // features per wave
   static constexpr int NKS = FW / 32;          // k-steps of a wave's partial scores
@@ -261,8 +261,8 @@ struct XsGeom {
   static constexpr int PF = 4;                 // key tiles a wave keeps in flight (in situ, 768 sequences in 3 lanes: 2 -> 5.92, 3 -> 5.70, 4 -> 5.65, 6 -> 6.0 ms per step)
   static constexpr int RS = 2 * FW + 32;       // bytes per staged key row: +32 makes the transposed reads of 8 rows hit 64 different banks
   static constexpr int STRIP = 16 * RS;        // one wave's staging strip (private: no barrier)
-  static constexpr int S_OFF = 4 * STRIP;      // partial-score exchange: [2 buffers][4 waves][64 lanes] f32x4
-  static constexpr int LDS = S_OFF + 2 * 4 * 1024;
+  static constexpr int S_OFF = 4 * STRIP;      // partial-score exchange: [2 buffers][RB rows][4 waves][64 lanes] f32x4
+  static constexpr int LDS = S_OFF + 2 * RB * 4 * 1024;
 };
 }  // namespace
 
@@ -285,13 +285,25 @@ struct XsGeom {
 // ~200 registers, 35 KB of LDS: two blocks per CU, 8 waves x 4 tiles x 6 KB = 192 KB of loads in flight per CU.
 // The halves' partials (contexts relative to their own reference, reference, denominator) are merged by dec_xv_project_kernel.
 // Deterministic: a row's numbers depend on nothing but its own q' and xa.
-template <int D>
-__global__ __launch_bounds__(256, 2) void dec_xs_stream_kernel(XsParams p) {
-  using G = XsGeom<D>;
+// RB > 1 (prompt prefill: p.rows_per_seq consecutive rows attend to ONE sequence's xa): a block takes RB rows of a sequence through
+// the same pass -- RB sets of q', scores, references and accumulators against one stream of tiles and one set of transposed reads;
+// per row the arithmetic is that of RB = 1, operation for operation.  One block per CU (RB = 4: ~430 registers).
+template <int D, int RB>
+__global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void dec_xs_stream_kernel(XsParams p) {
+  using G = XsGeom<D, RB>;
   constexpr int FW = G::FW, NKS = G::NKS, NMT = G::NMT, PF = G::PF, RS = G::RS;
   extern __shared__ __attribute__((aligned(16))) char xs_smem[];
-  const int row = blockIdx.x / XS_SPLIT, sp = blockIdx.x % XS_SPLIT;
-  const int seq = p.row_seq ? p.row_seq[row] : row;
+  const int unit = blockIdx.x / XS_SPLIT, sp = blockIdx.x % XS_SPLIT;
+  // rows of this block: RB == 1: row = unit; RB > 1: sequence s = unit / groups, rows s * rows_per_seq + gi * RB + j
+  int row0, nrow;
+  if (RB == 1) { row0 = unit; nrow = 1; }
+  else {
+    const int groups = (p.rows_per_seq + RB - 1) / RB;
+    const int s_idx = unit / groups, gi = unit - s_idx * groups;
+    row0 = s_idx * p.rows_per_seq + gi * RB;
+    nrow = p.rows_per_seq - gi * RB < RB ? p.rows_per_seq - gi * RB : RB;
+  }
+  const int seq = p.row_seq ? p.row_seq[row0] : row0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int H = p.H, S = p.S;
   char* strip = xs_smem + wave * G::STRIP;
@@ -313,19 +325,23 @@ __global__ __launch_bounds__(256, 2) void dec_xs_stream_kernel(XsParams p) {
   for (int j = 0; j < PF; j++)
     if (T0 + j < NT) load_tile(img[j], T0 + j);
 
-  // the wave's slice of q' (B operand of the scores: head r, feature chunk g); heads >= H: zero
-  bf16x8 qf[NKS];
-  {
-    const bf16_t* qsrc = p.xq + ((long)row * H + (r < H ? r : 0)) * D + wave * FW + g * 8;
+  // the wave's slice of q' (B operand of the scores: head r, feature chunk g); heads >= H: zero; rows past the group: the last row's
+  bf16x8 qf[RB][NKS];
+#pragma unroll
+  for (int jr = 0; jr < RB; jr++) {
+    const int rw = row0 + (jr < nrow ? jr : nrow - 1);
+    const bf16_t* qsrc = p.xq + ((long)rw * H + (r < H ? r : 0)) * D + wave * FW + g * 8;
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) {
-      qf[ks] = *(const bf16x8*)(qsrc + ks * 32);
-      if (r >= H) qf[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      qf[jr][ks] = *(const bf16x8*)(qsrc + ks * 32);
+      if (r >= H) qf[jr][ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
 
-  f32x4 acc[NMT];
-  float m_ref = -INFINITY, m_seen = -INFINITY, l_part = 0.f;
+  f32x4 acc[RB][NMT];
+  float m_ref[RB], m_seen[RB], l_part[RB];
+#pragma unroll
+  for (int jr = 0; jr < RB; jr++) { m_ref[jr] = -INFINITY; m_seen[jr] = -INFINITY; l_part[jr] = 0.f; }
   char* st_wr = strip + r * RS + g * 16;                                       // staging write: key r, feature chunk g
   const char* tr_rd = strip + (g * 4 + (r >> 2)) * RS + (r & 3) * 8;           // transposed read: lane 4q+p -> key 4g+q, features 4p..4p+3
   char* s_wr = sbuf + wave * 1024 + lane * 16;
@@ -333,60 +349,74 @@ __global__ __launch_bounds__(256, 2) void dec_xs_stream_kernel(XsParams p) {
   const float scale = p.scale_log2e;
 
   auto tile = [&](const bf16x8 (&X)[NKS], int t, bool first) {
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+    const int boff = (t & 1) * (RB * 4096);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ks++) {
-      if (ks & 1) sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[ks], sb, 0, 0, 0);
-      else sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[ks], sa, 0, 0, 0);
+    for (int jr = 0; jr < RB; jr++) {
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ks++) {
+        if (ks & 1) sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[jr][ks], sb, 0, 0, 0);
+        else sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X[ks], qf[jr][ks], sa, 0, 0, 0);
+      }
+      *(f32x4*)(s_wr + boff + jr * 4096) = NKS > 1 ? sa + sb : sa;
     }
-    const int boff = (t & 1) * 4096;
-    *(f32x4*)(s_wr + boff) = NKS > 1 ? sa + sb : sa;
     // stage the quarter tile as it is (read back transposed below): private strip, the wave's own LDS operations stay in order
 #pragma unroll
     for (int ks = 0; ks < NKS; ks++) *(bf16x8*)(st_wr + ks * 64) = X[ks];
     __syncthreads();
-    const f32x4 s0 = *(const f32x4*)(s_rd + boff), s1 = *(const f32x4*)(s_rd + boff + 1024), s2 = *(const f32x4*)(s_rd + boff + 2048),
-                s3 = *(const f32x4*)(s_rd + boff + 3072);
-    const f32x4 sc = (s0 + s1) + (s2 + s3);
-    // lane: head r, keys 16 t + 4 g + j
-    float tv[4];
-    const int key0 = t * 16 + g * 4;
+    bf16x4 pb[RB];
+    const int key0 = t * 16 + g * 4;             // lane: head r, keys 16 t + 4 g + j
 #pragma unroll
-    for (int j = 0; j < 4; j++) tv[j] = key0 + j < S ? sc[j] * scale : -INFINITY;
-    float tmax = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
-    tmax = fmaxf(tmax, lane_xor16(tmax));
-    tmax = fmaxf(tmax, lane_xor32(tmax));
-    m_seen = fmaxf(m_seen, tmax);
-    if (first) m_ref = tmax;                     // the row's first tile always holds live keys
-    float pv[4];
+    for (int jr = 0; jr < RB; jr++) {
+      const char* sr = s_rd + boff + jr * 4096;
+      const f32x4 s0 = *(const f32x4*)(sr), s1 = *(const f32x4*)(sr + 1024), s2 = *(const f32x4*)(sr + 2048), s3 = *(const f32x4*)(sr + 3072);
+      const f32x4 sc = (s0 + s1) + (s2 + s3);
+      float tv[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) pv[j] = __builtin_amdgcn_exp2f(tv[j] - m_ref);
-    l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-    const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
-    const bf16x4 pb = __builtin_bit_cast(bf16x4, pp);
+      for (int j = 0; j < 4; j++) tv[j] = key0 + j < S ? sc[j] * scale : -INFINITY;
+      float tmax = fmaxf(fmaxf(tv[0], tv[1]), fmaxf(tv[2], tv[3]));
+      tmax = fmaxf(tmax, lane_xor16(tmax));
+      tmax = fmaxf(tmax, lane_xor32(tmax));
+      m_seen[jr] = fmaxf(m_seen[jr], tmax);
+      if (first) m_ref[jr] = tmax;               // the block's first tile always holds live keys
+      float pv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) pv[j] = __builtin_amdgcn_exp2f(tv[j] - m_ref[jr]);
+      l_part[jr] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+      const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+      pb[jr] = __builtin_bit_cast(bf16x4, pp);
+    }
 #pragma unroll
     for (int mt = 0; mt < NMT; mt++) {
       const bf16x4 xt = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(tr_rd + mt * 32));
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, pb, acc[mt], 0, 0, 0);
+#pragma unroll
+      for (int jr = 0; jr < RB; jr++) acc[jr][mt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xt, pb[jr], acc[jr][mt], 0, 0, 0);
     }
   };
 
-  // Softmax reference: the maximum of the row's FIRST tile (per head), never moved -- the accumulators are never rescaled.
+  // Softmax reference: the maximum of the block's FIRST tile (per row and head), never moved -- the accumulators are never rescaled.
   // p = exp2(t - m_ref) may then exceed 1; fp32 / bf16 carry it up to 2^127, and numerator and denominator share the reference, so the
   // result is exact.  Should a later tile exceed the reference by more than 2^100 (an attention peak of e^69 over the first 16 keys:
-  // unseen), the block repeats the row once with the maximum it then knows (every wave holds the same scores: a uniform decision).
+  // unseen), the block repeats its key range once with the maximum it then knows (every wave holds the same scores: a uniform decision).
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
-      if (__builtin_amdgcn_ballot_w64(m_seen > m_ref + 100.f) == 0ull) break;
-      m_ref = m_seen;
+      bool over = false;
+#pragma unroll
+      for (int jr = 0; jr < RB; jr++) over |= m_seen[jr] > m_ref[jr] + 100.f;
+      if (__builtin_amdgcn_ballot_w64(over) == 0ull) break;
+#pragma unroll
+      for (int jr = 0; jr < RB; jr++) m_ref[jr] = m_seen[jr];
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < PF; j++)
         if (T0 + j < NT) load_tile(img[j], T0 + j);
     }
-    l_part = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < NMT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jr = 0; jr < RB; jr++) {
+      l_part[jr] = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < NMT; mt++) acc[jr][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     for (int t0 = T0; t0 < NT; t0 += PF) {
 #pragma unroll
       for (int j = 0; j < PF; j++) {
@@ -399,17 +429,22 @@ __global__ __launch_bounds__(256, 2) void dec_xs_stream_kernel(XsParams p) {
     }
   }
 
-  // the block's partial: unnormalised contexts of its key range (relative to m_ref), its reference maximum and denominator
-  float l_head = l_part;
-  l_head += lane_xor16(l_head);
-  l_head += lane_xor32(l_head);
-  const long unit = (long)row * XS_SPLIT + sp;
-  if (r < H) {
-    float* dst = p.part_o + (unit * H + r) * D + wave * FW + g * 4;
+  // the block's partials: unnormalised contexts of its key range (relative to m_ref), its reference maximum and denominator
 #pragma unroll
-    for (int mt = 0; mt < NMT; mt++) *(f32x4*)(dst + mt * 16) = acc[mt];
+  for (int jr = 0; jr < RB; jr++) {
+    if (jr < nrow) {
+      float l_head = l_part[jr];
+      l_head += lane_xor16(l_head);
+      l_head += lane_xor32(l_head);
+      const long u = (long)(row0 + jr) * XS_SPLIT + sp;
+      if (r < H) {
+        float* dst = p.part_o + (u * H + r) * D + wave * FW + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt++) *(f32x4*)(dst + mt * 16) = acc[jr][mt];
+      }
+      if (wave == 0 && g == 0) *(float2*)(p.part_ml + (u * 16 + r) * 2) = make_float2(m_ref[jr], l_head);
+    }
   }
-  if (wave == 0 && g == 0) *(float2*)(p.part_ml + (unit * 16 + r) * 2) = make_float2(m_ref, l_head);
 }
 
 namespace {
@@ -422,12 +457,18 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   // decode step 6.25 -> 5.87 ms with two lanes.  CCX_XS_LDS_PAD overrides (experiments).
   static const int forced_pad = [] { const char* e = getenv("CCX_XS_LDS_PAD"); return e ? atoi(e) : -1; }();
   const int lds_pad = forced_pad >= 0 ? forced_pad : p.lds_pad;
+  // prompt prefill (rows_per_seq consecutive rows per sequence): four rows of a sequence share one pass over its xa
+  // (CCX_XS_PREFILL_ROWS=1: one row per block, as the decode steps)
+  static const int pf_rows = [] { const char* e = getenv("CCX_XS_PREFILL_ROWS"); return e ? atoi(e) : 4; }();
+  const bool multi = p.rows_per_seq > 1 && pf_rows == 4;
   static bool attr_set = false;
   if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   CCX_REQUIRE(ctx, lds_pad >= 0 && G::LDS + lds_pad <= 160 * 1024, "xs cross attention: LDS claim %d too large", lds_pad);
+  CCX_REQUIRE(ctx, p.rows_per_seq <= 1 || p.rows % p.rows_per_seq == 0, "xs cross attention: %d rows are not a multiple of %d rows per sequence", p.rows, p.rows_per_seq);
   const dim3 small_grid(p.H, ccx_cdiv(p.rows, 16));
   const double wbytes = (double)p.H * 64 * D * 2;
   if (p.x) {
@@ -442,7 +483,13 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   {
     ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xs_stream_kernel<768>" : "dec_xs_stream_kernel", 4.0 * p.rows * 16 * (double)p.S * D,
                       (double)p.rows * ((double)p.S * D * 2 + p.H * D * 2.0 + XS_SPLIT * p.H * D * 4.0));
-    hipLaunchKernelGGL(dec_xs_stream_kernel<D>, dim3(p.rows * XS_SPLIT), dim3(256), G::LDS + lds_pad, stream, p);
+    if (multi) {
+      const int units = p.rows / p.rows_per_seq * ccx_cdiv(p.rows_per_seq, 4);
+      constexpr int lds4 = XsGeom<D, 4>::LDS;
+      hipLaunchKernelGGL((dec_xs_stream_kernel<D, 4>), dim3(units * XS_SPLIT), dim3(256), lds4, stream, p);
+    } else {
+      hipLaunchKernelGGL((dec_xs_stream_kernel<D, 1>), dim3(p.rows * XS_SPLIT), dim3(256), G::LDS + lds_pad, stream, p);
+    }
   }
   CCX_CHECK_LAUNCH(ctx);
   {

@@ -1060,6 +1060,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
         xp.Wv = L.Wckv + (long)D * D; xp.bv = L.bckv + D; xp.out = dattn;
         xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
         xp.lds_pad = (w->cross_lds_pad > 0 && !pre) ? 65536 : 0;
+        xp.rows_per_seq = pre ? prefill_rows : 0;
         TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
         if (xs_fused && pend_n > 0) { float* t = cur; cur = other; other = t; pend_n = 0; }
       } else if (xs_fused) {

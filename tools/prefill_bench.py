@@ -1,5 +1,6 @@
 """How long is the prompt prefill of a 384-sequence decode group?  Times decode_greedy(sample_len=1) (prefill + the first token) for
-the pinned schedule's two prompt lengths, with the one-pass prefill (default) and fed step by step (CCX_PREFILL=0)."""
+the given prompt lengths (default 4, 10, 16; B=<sequences> in the environment), prefilled in passes of 16 positions (default) and fed
+step by step (CCX_PREFILL=0)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +15,7 @@ m.log_mel(audio, [16000 * 30] * B)
 m.encode(B)
 torch.cuda.synchronize()
 rng = np.random.default_rng(0)
-for P in (4, 10, 16):
+for P in [int(a) for a in sys.argv[1:]] or (4, 10, 16):
     prompts = [[m.rules.sot_prev] + list(rng.integers(1000, 20000, P - 2)) + [m.rules.sot] for _ in range(B)]
     for mode in ("1", "0"):
         os.environ["CCX_PREFILL"] = mode
