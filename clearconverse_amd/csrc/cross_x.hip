@@ -481,7 +481,7 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   }
   CCX_CHECK_LAUNCH(ctx);
   {
-    ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xs_stream_kernel<768>" : "dec_xs_stream_kernel", 4.0 * p.rows * 16 * (double)p.S * D,
+    ccx_prof_scope ps(ctx, stream, D == 768 ? (multi ? "dec_xs_stream_kernel<768,4>" : "dec_xs_stream_kernel<768,1>") : "dec_xs_stream_kernel", 4.0 * p.rows * 16 * (double)p.S * D,
                       (double)p.rows * ((double)p.S * D * 2 + p.H * D * 2.0 + XS_SPLIT * p.H * D * 4.0));
     if (multi) {
       const int units = p.rows / p.rows_per_seq * ccx_cdiv(p.rows_per_seq, 4);

@@ -109,7 +109,7 @@ def test_pmc_reduction_reads_the_rows_of_the_xstream_kernel_off_its_grid(tmp_pat
             w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value"])
             for d, name, grid, val in rows:
                 w.writerow([d, name, grid, counter, val])
-    name = "void dec_xs_stream_kernel<768>(XsParams)"
+    name = "void dec_xs_stream_kernel<768, 1>(XsParams)"
     write(tmp_path / "f.csv", "FETCH_SIZE", [(d, name, 256 * 2 * 256, 292000.0 / 8) for d in (1, 2, 3) for _ in range(8)]
           + [(4, name, 240 * 2 * 256, 274000.0 / 8) for _ in range(8)])
     write(tmp_path / "w.csv", "WRITE_SIZE", [(d, name, 256 * 2 * 256, 18400.0 / 8) for d in (1, 2, 3) for _ in range(8)]
@@ -118,10 +118,10 @@ def test_pmc_reduction_reads_the_rows_of_the_xstream_kernel_off_its_grid(tmp_pat
     subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_to_json.py"), str(tmp_path / "f.csv"), str(tmp_path / "w.csv"), str(out), "test note"],
                    check=True, capture_output=True)
     all_ = json.loads(out.read_text())
-    d = all_["dec_xs_stream_kernel<768>"]
+    d = all_["dec_xs_stream_kernel<768,1>"]
     assert d["launches"] == 3 and d["sequences_per_launch"] == 256 and d["sequences_per_launch_seen"] == [240, 256]
     assert d["hbm_bytes_per_launch"] == pytest.approx((2 * 292000.0 + 18400.0) * 1024.0)
-    assert all_["dec_xs_stream_kernel<768> @240"]["launches"] == 1
+    assert all_["dec_xs_stream_kernel<768,1> @240"]["launches"] == 1
 
 
 def test_bench_prices_the_cross_attention_with_the_bytes_of_the_formulation_it_runs():
