@@ -56,7 +56,7 @@ PROTOTYPES = {
     "ccx_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
     "ccx_peak_normalize": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _f, _vp]),
     "ccx_row_variance": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
-    "ccx_cross_attention_xa": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ccx_cross_attention_xa": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ccx_cosine_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ccx_speaker_profiles": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ccx_resample_sinc": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i, _vp]),

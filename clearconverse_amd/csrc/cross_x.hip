@@ -535,8 +535,8 @@ __global__ void xs_bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __re
 }  // namespace
 
 extern "C" int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const float* wk_host, const float* wv_host, const float* bv_host,
-                                      const uint16_t* xa_dev, const int* row_seq_host, int rows, int n_seq, int n_head, int n_ctx,
-                                      float* out_dev, void* stream_) {
+                                      const uint16_t* xa_dev, const int* row_seq_host, int rows_per_seq, int rows, int n_seq, int n_head,
+                                      int n_ctx, float* out_dev, void* stream_) {
   if (!ctx) return CCX_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const int H = n_head, D = 64 * n_head, S = n_ctx;
@@ -545,6 +545,11 @@ extern "C" int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const fl
   if (row_seq_host)
     for (int i = 0; i < rows; i++) CCX_REQUIRE(ctx, row_seq_host[i] >= 0 && row_seq_host[i] < n_seq, "cross_attention_xa: row_seq[%d] out of range", i);
   else CCX_REQUIRE(ctx, rows <= n_seq, "cross_attention_xa: more rows than sequences without a row map");
+  if (rows_per_seq > 1) {
+    CCX_REQUIRE(ctx, row_seq_host && rows % rows_per_seq == 0, "cross_attention_xa: rows_per_seq needs a row map and a multiple of it in rows");
+    for (int i = 0; i < rows; i++)
+      CCX_REQUIRE(ctx, row_seq_host[i] == row_seq_host[i - i % rows_per_seq], "cross_attention_xa: row %d is not in its group's sequence", i);
+  }
   std::vector<bf16_t> wkt((size_t)D * D), wv((size_t)D * D);
   for (int hh = 0; hh < H; hh++)
     for (int f = 0; f < D; f++)
@@ -569,6 +574,7 @@ extern "C" int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const fl
   memset(&p, 0, sizeof(p));
   p.q = q_dev; p.WkT = d_wkt; p.xq = d_xq; p.X = xa_dev; p.x_seq_stride = (long)S * D; p.row_seq = d_rs; p.Wv = d_wv; p.bv = d_bv; p.out = d_out; p.part_o = d_po; p.part_ml = d_pml;
   p.rows = rows; p.H = H; p.S = S; p.D = D; p.scale_log2e = 0.125f * 1.4426950408889634f;
+  p.rows_per_seq = rows_per_seq > 1 ? rows_per_seq : 0;
   int rc = ccx_launch_xs_cross_attention(ctx, p, stream);
   if (rc == CCX_OK) {
     const long n = (long)rows * D;

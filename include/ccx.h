@@ -68,10 +68,12 @@ int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t s
  * back/api.py:1286-1292 through transcribe()) -- computed the way the decode path of ccx_whisper_decode computes it for more than 16
  * sequences: against the encoder output itself (csrc/cross_x.hip), no K/V ever materialised.  q_dev [rows][64 n_head] f32 (bias
  * included), wk / wv [64 n_head][64 n_head] f32 and bv on the HOST, xa_dev bf16 [n_seq][n_ctx][64 n_head], row_seq (host, may be
- * null = identity) maps rows to sequences, out_dev [rows][64 n_head] f32.  Synchronises the stream.  For kernel parity tests. */
+ * null = identity) maps rows to sequences, out_dev [rows][64 n_head] f32.  rows_per_seq > 1: consecutive groups of that many rows
+ * belong to one sequence each (the prompt prefill: four rows of a group then share one pass over the sequence's xa), else 0.
+ * Synchronises the stream.  For kernel parity tests. */
 int ccx_cross_attention_xa(ccx_ctx* ctx, const float* q_dev, const float* wk_host, const float* wv_host, const float* bv_host,
-                           const uint16_t* xa_dev, const int* row_seq_host, int rows, int n_seq, int n_head, int n_ctx, float* out_dev,
-                           void* stream);
+                           const uint16_t* xa_dev, const int* row_seq_host, int rows_per_seq, int rows, int n_seq, int n_head, int n_ctx,
+                           float* out_dev, void* stream);
 /* Embedding-quality weight of `_build_speaker_profiles`: out[b] = torch.var(x[b][0 .. n_b)) (unbiased; reference back/api.py:939).
  * fp64 accumulation in a fixed order: a row's value does not depend on its batch mates. */
 int ccx_row_variance(ccx_ctx* ctx, const float* x_dev, int64_t stride, const int* n_samples_dev, int B, float* out_dev, void* stream);

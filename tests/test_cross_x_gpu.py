@@ -35,7 +35,7 @@ def _reference(q, wk, wv, bv, xa, row_seq, H):
     return out
 
 
-def _run(ccx_ctx, q, wk, wv, bv, xa, row_seq, H):
+def _run(ccx_ctx, q, wk, wv, bv, xa, row_seq, H, rows_per_seq=0):
     from clearconverse_amd import _lib
     lib = _lib.load()
     rows, D = q.shape
@@ -46,7 +46,7 @@ def _run(ccx_ctx, q, wk, wv, bv, xa, row_seq, H):
     wk_h, wv_h, bv_h = (np.ascontiguousarray(t.numpy(), dtype=np.float32) for t in (wk, wv, bv))
     rs = None if row_seq is None else (C.c_int * rows)(*[int(v) for v in row_seq])
     ccx_ctx.check(lib.ccx_cross_attention_xa(ccx_ctx.handle, qd.data_ptr(), wk_h.ctypes.data, wv_h.ctypes.data, bv_h.ctypes.data,
-                                             xd.data_ptr(), rs, rows, n_seq, H, S, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                             xd.data_ptr(), rs, rows_per_seq, rows, n_seq, H, S, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
                   "ccx_cross_attention_xa")
     return out.cpu()
 
@@ -106,6 +106,22 @@ def test_rows_share_sequences_and_do_not_see_each_other(ccx_ctx):
         assert torch.equal(alone[0], got[r]), r
     again = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H)
     assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("H,P", [(12, 9), (12, 16), (2, 5), (6, 4), (8, 1)])
+def test_prompt_rows_of_a_sequence_share_one_pass(ccx_ctx, H, P):
+    """The prefill form: groups of P consecutive rows per sequence, FOUR rows of a group per streaming block (dec_xs_stream_kernel<D, 4>;
+    ragged last blocks at P = 9 and 5, P = 1 falls back to one row per block).  Against explicit K / V, and bit-identical to the same
+    rows taken one per block (rows_per_seq = 0)."""
+    n_seq, S = 3, 1500
+    rs = [s for s in range(n_seq) for _ in range(P)]
+    q, wk, wv, bv, xa, _ = _case(300 + H + P, H, S, len(rs), n_seq, q_gain=1.5, row_seq=rs)
+    got = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H, rows_per_seq=P)
+    want = _reference(q, wk, wv, bv, xa, rs, H)
+    for r in range(len(rs)):
+        within("cross attention against xa: prompt rows sharing a pass, rel-L2", float((got[r] - want[r]).norm() / want[r].norm()), TOL, (H, P, r))
+    single = _run(ccx_ctx, q, wk, wv, bv, xa, rs, H)
+    assert torch.equal(single, got)
 
 
 def test_argument_errors(ccx_ctx):

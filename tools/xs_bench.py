@@ -26,7 +26,7 @@ def main():
             if it == 2:
                 ctx.prof_enable(True)
             ctx.check(lib.ccx_cross_attention_xa(ctx.handle, q.data_ptr(), wk.ctypes.data, wv.ctypes.data, bv.ctypes.data, xa.data_ptr(), None,
-                                                 rows, rows, H, S, out.data_ptr(), st))
+                                                 0, rows, rows, H, S, out.data_ptr(), st))
         torch.cuda.synchronize()
         recs = ctx.prof_records()
         ctx.prof_enable(False)
