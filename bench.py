@@ -417,7 +417,9 @@ def main():
     # region's own group size: `roofline.achieved` is measured AT the launch shape the timed region runs (a cross-attention launch takes
     # as long as the CU with the most blocks: 240 rows = 480 blocks leave the chip unevenly loaded, 256 rows = 512 blocks do not).
     def n_lanes(b):                       # as ccx_whisper_decode cuts a group into lanes
-        return (3 if xstream else 2) if b >= 640 else (3 if b >= 144 else (2 if b >= 96 else 1))
+        if xstream:
+            return 3 if b >= 320 else 1
+        return 2 if b >= 640 else (3 if b >= 144 else (2 if b >= 96 else 1))
     nl_real = n_lanes(Bd)
     Bp = Bd - 16 * nl_real
     if n_lanes(Bp) != nl_real or nl_real == 1:

@@ -1294,7 +1294,10 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     // 710.0, 3 lanes 698.0 ms; with 768-sequence groups: 1 lane 721.5, 2 lanes 676.6, 3 lanes 687.5, 4 lanes 704.0 ms
     // with the cross attention against the encoder output (half the bytes: the chain weighs more): 768-sequence groups 2 lanes 561.3,
     // 3 lanes 557.9 ms per pipeline step
-    else nl = B >= 640 ? (w->xs_on ? 3 : 2) : (B >= 144 ? 3 : (B >= 96 ? 2 : 1));
+    // ... 384-sequence groups 3 lanes 598.6, 2 lanes 616.6 ms; 192-sequence groups (the sequential schedule) 1 lane 768.1, 2 lanes
+    // 779.5, 3 lanes 793.2 ms: below ~128 rows per lane the streaming launches no longer fill the chip
+    else if (w->xs_on) nl = B >= 320 ? 3 : 1;
+    else nl = B >= 640 ? 2 : (B >= 144 ? 3 : (B >= 96 ? 2 : 1));
     if (nl > ccx_whisper::kMaxLanes) nl = ccx_whisper::kMaxLanes;
     while (nl > 1 && B / nl < 16) nl--;
   }
