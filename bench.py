@@ -39,7 +39,7 @@ MFMA_KERNELS = ("gemm_bf16_nt_kernel", "enc_attention_kernel")
 
 def enc_flops_per_window(d):
     """SURVEY.md section 8d formula (encoder incl. conv stem); the second figure is the cross-K/V projection of the 12 decoder layers,
-    which round 3's decode no longer computes for groups of more than 16 sequences (the cross attention reads the encoder output
+    which round 3's decode no longer computes for groups of more than 80 sequences (the cross attention reads the encoder output
     itself, csrc/cross_x.hip) -- reported, not counted."""
     D, L, S = d.n_audio_state, d.n_audio_layer, d.n_audio_ctx
     enc = 2 * (3000 * D * 3 * d.n_mels + S * D * 3 * D + L * (S * (4 * D * D + 2 * D * 4 * D) + 2 * S * S * D))
@@ -630,7 +630,7 @@ def main():
                "tokens_decoded": n_tokens, "parallelism": f"clip-sharded x{world}",
                "encoder_gflop_per_window": round((enc_f + (0 if xstream else cross_f)) / 1e9, 1),
                "cross_attention": ("against the encoder output: one pass over xa per layer and sequence serves all heads, no K/V caches "
-                                   "(csrc/cross_x.hip; decodes of <= 16 sequences keep per-layer K/V)" if xstream else "per-layer K/V caches (CCX_CROSS_X=0)")}
+                                   "(csrc/cross_x.hip; decodes of <= 80 sequences keep per-layer K/V)" if xstream else "per-layer K/V caches (CCX_CROSS_X=0)")}
         if pipeline:
             cfg["schedule"] = ("pinned synthetic schedule (SURVEY.md 8d): per clip 2 regular + 2 overlap-bearing segments -> "
                                "6 Whisper windows, 4 separator regions, 62 x-vector crops; VAD (51 x 5 s chunks) and diarization "

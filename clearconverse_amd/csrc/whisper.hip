@@ -135,10 +135,11 @@ struct ccx_whisper {
   int cross_lds_pad = 0;                     // see ccx_whisper_decode: occupancy cap of the cross-attention blocks while lanes overlap
   int cross_stream = 0;                      // 1: lean-streaming cross attention (dec_cross_stream_kernel) for batches > 16
   int fuse_cross_q = 1;                      // 1: batches <= 16 compute the cross-attention query inside the attention blocks
-  // Cross attention against the encoder output (cross_x.hip) for decodes of more than 16 sequences: no per-layer K/V caches at all
+  // Cross attention against the encoder output (cross_x.hip) for decodes of more than 80 sequences: no per-layer K/V caches beyond those
   // (42 GB at 768 sequences), half the bytes per step.  xs_on: the instance was built for it (widths cross_x.hip instantiates,
-  // CCX_CROSS_X != 0 at finalize); the K/V caches then hold kv_cap = 16 sequences and are filled from xa at the start of a decode
-  // of <= 16 sequences (kv_ready = sequences valid since the last encode).
+  // CCX_CROSS_X != 0 at finalize); the K/V caches then hold kv_cap <= 80 sequences and are filled from xa at the start of a decode
+  // that takes the K/V path (kv_ready = sequences valid since the last encode).
+  static constexpr int kKvSeqs = 80;         // sequences the K/V caches of an X-stream instance hold (4.5 GB at small.en)
   bool xs_on = false, xs_active = false, xs_fuse_q = true;
   int kv_cap = 0, kv_ready = 0;
   bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
@@ -509,7 +510,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
   {
     const char* e = getenv("CCX_CROSS_X");      // 0: round 2's per-layer cross K/V caches for every sequence (A/B)
     w->xs_on = (!e || atoi(e) != 0) && d.n_text_state == D && d.n_text_head == H && ccx_xs_supported(D, H);
-    w->kv_cap = w->xs_on ? (B < 16 ? B : 16) : B;
+    w->kv_cap = w->xs_on ? (B < ccx_whisper::kKvSeqs ? B : ccx_whisper::kKvSeqs) : B;
   }
   for (int l = 0; l < d.n_text_layer; l++) {
     const std::string p = "decoder.blocks." + std::to_string(l) + ".";
@@ -730,12 +731,15 @@ static int project_cross_kv(ccx_whisper* w, int n, hipStream_t stream) {
 }
 // which cross attention a decode of B sequences uses, and the K/V it needs
 static int select_cross_path(ccx_whisper* w, int B, hipStream_t stream) {
-  // CCX_CROSS_X_MIN_ROWS (read per call: tests flip it): smallest decode that takes the X-stream path.  Default 17: up to 16 rows the
-  // chain is latency-bound launch by launch and the split-KV kernels with the fused query are faster.  Within one path a sequence's
-  // numbers do not depend on its batch mates; across the two paths they agree to rounding (tests/test_whisper_gpu.py).
+  // CCX_CROSS_X_MIN_ROWS (read per call: tests flip it): smallest decode that takes the X-stream path.  Default 81: the streaming kernel
+  // runs two blocks per sequence, and below ~160 blocks they do not fill the chip -- Whisper only, 24 / 32 / 48 / 64 / 96 x 30 s:
+  // 300.7 / 311.8 / 340.0 / 357.9 / 404.3 ms per batch on the X-stream path against 208.6 / 223.3 / 289.4 / 329.3 / 427.2 on per-layer
+  // K / V (split-KV kernels with the fused query up to 16 sequences, the lean streaming kernel above).  Within one path a sequence's
+  // numbers do not depend on its batch mates; across the paths they agree to rounding (tests/test_whisper_gpu.py).  Decodes the K / V
+  // caches cannot hold (kv_cap sequences) always take the X-stream path.
   const char* e = getenv("CCX_CROSS_X_MIN_ROWS");
-  const int min_rows = e ? atoi(e) : 17;
-  w->xs_active = w->xs_on && B >= min_rows;
+  const int min_rows = e ? atoi(e) : ccx_whisper::kKvSeqs + 1;
+  w->xs_active = w->xs_on && (B >= min_rows || B > w->kv_cap);
   { const char* f = getenv("CCX_XS_FUSE_Q"); w->xs_fuse_q = !f || atoi(f) != 0; }      // read per call: tests flip it
   if (w->xs_on && !w->xs_active && w->kv_ready < B) TRY(project_cross_kv(w, B, stream));
   return CCX_OK;
@@ -786,7 +790,7 @@ int ccx_whisper_encode(ccx_whisper* w, int B, float* xa_out, void* stream_) {
   }
   TRY(ccx_launch_layernorm(ctx, w->x, D, w->lnp_g, w->lnp_b, w->xa, xa_out, D, M, D, 1e-5f, stream));
   TRY(scratch_release(w, stream));
-  // cross-attention K/V: with the X-stream cross attention only decodes of <= 16 sequences use them and project them themselves
+  // cross-attention K/V: with the X-stream cross attention only decodes of <= 80 sequences use them and project them themselves
   w->kv_ready = 0;
   if (!w->xs_on) TRY(project_cross_kv(w, B, stream));
   return CCX_OK;
@@ -1045,7 +1049,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     if (w->xs_active) {
-      // decodes of more than 16 sequences: one pass over the encoder output serves all heads (cross_x.hip)
+      // decodes of more than 80 sequences: one pass over the encoder output serves all heads (cross_x.hip)
       if (ablate != 1) {
         XsParams xp;
         memset(&xp, 0, sizeof(xp));

@@ -65,7 +65,7 @@ int ccx_peak_normalize(ccx_ctx* ctx, const float* x_dev, float* y_dev, int64_t s
                        float eps, void* stream);
 /* One decoder layer's cross attention as a stand-alone operator: out[r] = softmax(q[r] K^T / 8) V per head with K = xa Wk^T,
  * V = xa Wv^T + bv -- openai-whisper MultiHeadAttention.qkv_attention with xa (called per layer and decode step from
- * back/api.py:1286-1292 through transcribe()) -- computed the way the decode path of ccx_whisper_decode computes it for more than 16
+ * back/api.py:1286-1292 through transcribe()) -- computed the way the decode path of ccx_whisper_decode computes it for more than 80
  * sequences: against the encoder output itself (csrc/cross_x.hip), no K/V ever materialised.  q_dev [rows][64 n_head] f32 (bias
  * included), wk / wv [64 n_head][64 n_head] f32 and bv on the HOST, xa_dev bf16 [n_seq][n_ctx][64 n_head], row_seq (host, may be
  * null = identity) maps rows to sequences, out_dev [rows][64 n_head] f32.  rows_per_seq > 1: consecutive groups of that many rows
@@ -144,8 +144,8 @@ int ccx_whisper_logmel(ccx_whisper* w, const float* audio_dev, int64_t stride, c
                        const int* seek_frames, int B, float* mel_out_dev, void* stream);
 /* Alternative input: take a ready [B, n_mels, 3000] f32 mel (BASELINE config 2 "mel [8,80,3000]"). */
 int ccx_whisper_set_mel(ccx_whisper* w, const float* mel_dev, int B, void* stream);
-/* AudioEncoder.forward for the B staged windows.  The encoder output (bf16) stays with the instance: decodes of more than 16 sequences
- * read it directly in their cross attention (csrc/cross_x.hip), decodes of <= 16 sequences project the per-layer cross-attention K / V
+/* AudioEncoder.forward for the B staged windows.  The encoder output (bf16) stays with the instance: decodes of more than 80 sequences
+ * read it directly in their cross attention (csrc/cross_x.hip), decodes of <= 80 sequences project the per-layer cross-attention K / V
  * of their sequences out of it when they start (with CCX_CROSS_X=0 at ccx_whisper_finalize this call projects K / V for all B, as in
  * openai-whisper's kv_cache hooks).
  * xa_out_dev (optional): [B, n_audio_ctx, n_audio_state] f32 copy of the encoder output. */

@@ -196,14 +196,20 @@ def _batch_mates(m, dims, sd, dev, n, prompts, reps, sample_len, monkeypatch, la
     default small-batch path (split-KV kernels) must agree with it to rounding."""
     m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
     a_small = m.decode_greedy(prompts, sample_len=sample_len)
-    monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
+    monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")          # by default decodes of <= 80 sequences take the K / V path
     a = m.decode_greedy(prompts, sample_len=sample_len)
-    monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
     big = dev.repeat(reps, 1).contiguous()
     m.log_mel(big, n * reps); m.encode(4 * reps)
     if lanes:
         monkeypatch.setenv("CCX_DEC_LANES", str(lanes))
     b = m.decode_greedy(prompts * reps, sample_len=sample_len)
+    monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
+    if 4 * reps <= 80:
+        # the default path of 17 .. 80 sequences: per-layer K / V through the lean streaming kernel (round 2's large-batch path)
+        bd = m.decode_greedy(prompts * reps, sample_len=sample_len)
+        for i in range(4 * reps):
+            assert bd[i]["tokens"] == a_small[i % 4]["tokens"], i
+            assert abs(bd[i]["sum_logprob"] - a_small[i % 4]["sum_logprob"]) < 1e-3, i
     for i in range(4 * reps):
         assert b[i]["tokens"] == a[i % 4]["tokens"], i
         assert abs(b[i]["sum_logprob"] - a[i % 4]["sum_logprob"]) < 1e-4, i
@@ -331,7 +337,9 @@ def test_fused_cross_query_equals_two_launches(ccx_ctx, monkeypatch):
                     assert a["no_speech_prob"] == b["no_speech_prob"]
         monkeypatch.setenv("CCX_FUSE_CROSS_Q", "1")
         small = m.decode([base[i % 5] for i in range(16)], sample_len=7)
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "17")       # the 20 on the X-stream path (default: K / V up to 80 sequences)
         large = m.decode([base[i % 5] for i in range(20)], sample_len=7)
+        monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
         # (gain-3 weights: sharper softmaxes and smaller margins than the other path-equivalence tests, whose bound is 2e-3; the 20
         #  sequences take the cross attention against the encoder output, the 16 the split-KV kernels on K / V caches)
         orc = _oracle(dims, sd)
@@ -416,6 +424,7 @@ def test_xstream_query_projection_inside_the_expansion_equals_three_launches(ccx
         m.log_mel(big, n * 10); xa = m.encode(40, return_xa=True).cpu()
         prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, 88, 99, rules.sot]] * 10
         orc = _oracle(dims, sd)
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")        # 40 sequences would take the K / V path by default
         for prefill in ("1", "0"):
             monkeypatch.setenv("CCX_PREFILL", prefill)
             monkeypatch.setenv("CCX_XS_FUSE_Q", "1")
@@ -530,7 +539,9 @@ def test_prompt_prefill_equals_stepwise_prompt_feeding(ccx_ctx, monkeypatch):
             _oracle_accepts(orc, xa[i:i + 1], prompts[i], ax[i], 10, 0.08)        # prefill rows through the X-stream kernel (row -> sequence map)
         big = dev.repeat(10, 1).contiguous()
         m.log_mel(big, n * 10); m.encode(40)
-        c = m.decode_greedy(prompts * 10, sample_len=10)                          # 40 x 16 = 640 prefill rows, then lanes
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
+        c = m.decode_greedy(prompts * 10, sample_len=10)                          # 40 x 16 = 640 prefill rows, X-stream path
+        monkeypatch.delenv("CCX_CROSS_X_MIN_ROWS")
         for i in range(40):
             assert c[i]["tokens"] == ax[i % 4]["tokens"], i
             assert abs(c[i]["sum_logprob"] - ax[i % 4]["sum_logprob"]) < 1e-4, i
@@ -563,6 +574,7 @@ def test_long_prompts_are_prefilled_in_passes_of_16_positions(ccx_ctx, monkeypat
             if reps > 1:
                 big = dev.repeat(reps, 1).contiguous()
                 m.log_mel(big, n * reps); m.encode(B)
+                monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")        # the 40 on the X-stream path (default: K / V up to 80 sequences)
             a = m.decode_greedy(prompts * reps, sample_len=8)
             s1 = m.decode(prompts * reps, sample_len=6, temperature=0.7, seed=5)
             monkeypatch.setenv("CCX_PREFILL", "0")
