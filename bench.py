@@ -614,14 +614,18 @@ def main():
                        sample=sample)
             if pipeline:
                 # one full clip WAS timed end to end through the same oracle pipeline on a GPU box's host cores (tools/cpu_full_clip.py,
-                # once per round, committed): how far the extrapolation above is from it
+                # ~100 s of CPU work: once per round, committed).  That MEASURED figure is `value`; this run's bounded-sample
+                # extrapolation stays beside it as `extrapolated`
                 full = sorted((ROOT / "profiles").glob("r*_cpu_full_clip.json"))
                 if full:
                     fc = json.loads(full[-1].read_text())
-                    cpu["measured_full_clip"] = dict(file=f"profiles/{full[-1].name}", xrt=fc["xrt"], total_s=fc["total_s"], threads=fc["threads"],
-                                                     extrapolated_over_measured=round(xrt / fc["xrt"], 3))
-                    cpu["sample"] += (f"; one full clip measured end to end on {fc['threads']} threads of a GPU box: {fc['total_s']} s = {fc['xrt']} xRT "
-                                      f"({full[-1].name}), this run's extrapolation / that measurement = {xrt / fc['xrt']:.2f}")
+                    cpu = dict(value=fc["xrt"], unit="xRT (audio-sec/wall-sec)", cores=fc["threads"], kind="port",
+                               method=f"measured end to end: ONE full 30 s clip through the oracle pipeline on {fc['threads']} host threads of a GPU box "
+                                      f"(tools/cpu_full_clip.py, committed as profiles/{full[-1].name})",
+                               sample=f"one full 30 s clip under the pinned schedule (6 Whisper calls x 224 tokens, 4 separator regions, 62 x-vector crops, "
+                                      f"VAD + diarization): {fc['total_s']} s of CPU work = {fc['xrt']} xRT",
+                               extrapolated=dict(value=round(xrt, 3), cores=threads, sample=sample, over_measured=round(xrt / fc["xrt"], 3),
+                                                 method="this run: bounded op samples x one clip's op counts"))
 
         enc_f, cross_f = enc_flops_per_window(dims)
         cfg = {"workload": "full_pipeline_vad_diarize_separate_transcribe (BASELINE configs[3])" if pipeline
@@ -629,6 +633,7 @@ def main():
                "clips_per_gpu": B, "clip_seconds": 30, "sample_len": args.sample_len, "whisper_calls": n_calls,
                "tokens_decoded": n_tokens, "parallelism": f"clip-sharded x{world}",
                "encoder_gflop_per_window": round((enc_f + (0 if xstream else cross_f)) / 1e9, 1),
+               "cross_path": sorted({r.get("cross_path", "unknown") for r in res["records"]}) if res else None,
                "cross_attention": ("against the encoder output: one pass over xa per layer and sequence serves all heads, no K/V caches "
                                    "(csrc/cross_x.hip; decodes of <= 80 sequences keep per-layer K/V)" if xstream else "per-layer K/V caches (CCX_CROSS_X=0)")}
         if pipeline:

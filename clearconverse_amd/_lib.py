@@ -73,6 +73,7 @@ PROTOTYPES = {
     "ccx_whisper_encode": (_i, [_vp, _i, _vp, _vp]),
     "ccx_whisper_decoder_logits": (_i, [_vp, _i32p, _i, _i, _vp, _vp]),
     "ccx_whisper_decode_greedy": (_i, [_vp, _i32p, _i32p, _i, _i, _i, _i32p, _i32p, _fp, _fp, _vp]),
+    "ccx_whisper_last_cross_path": (_i, [_vp]),
     "ccx_whisper_prepare_lanes": (_i, [_vp, _vp]),
     "ccx_whisper_trace_lanes": (_i, [_vp, C.c_char_p, _i]),
     "ccx_whisper_decode": (_i, [_vp, _i32p, _i32p, _i, _i, _i, _f, C.c_uint64, _i32p, _i32p, _fp, _fp, _vp]),

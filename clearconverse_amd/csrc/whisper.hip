@@ -141,6 +141,7 @@ struct ccx_whisper {
   // that takes the K/V path (kv_ready = sequences valid since the last encode).
   static constexpr int kKvSeqs = 80;         // sequences the K/V caches of an X-stream instance hold (4.5 GB at small.en)
   bool xs_on = false, xs_active = false, xs_fuse_q = true;
+  int last_cross_path = -1;                  // ccx_whisper_last_cross_path: 0 kv16, 1 kv_stream, 2 xa_stream
   int kv_cap = 0, kv_ready = 0;
   bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
   float *xs_po = nullptr, *xs_pml = nullptr, *pf_xs_po = nullptr, *pf_xs_pml = nullptr;   // key-half partials (cross_x.h)
@@ -1234,6 +1235,8 @@ int ccx_whisper_decoder_logits(ccx_whisper* w, const int32_t* tokens, int B, int
   return CCX_OK;
 }
 
+int ccx_whisper_last_cross_path(ccx_whisper* w) { return w ? w->last_cross_path : -1; }
+
 int ccx_whisper_prepare_lanes(ccx_whisper* w, void* stream_) {
   if (!w) return CCX_ERR_ARG;
   CCX_REQUIRE(w->ctx, w->finalized, "whisper: not finalized");
@@ -1336,6 +1339,8 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     }
     nl = n;
   }
+  // which cross attention the steps of this decode run (lane 0; a short last lane of <= 16 rows takes the <= 16-row kernels of its path)
+  w->last_cross_path = w->xs_active ? 2 : ((w->cross_stream && lanes[0].B > 16) ? 1 : 0);
   if (prefill) {
     TRY(run_prefill(w, prompt_ids, prompt_lens, max_prompt, B, max_pl, sample_len, stream));
     // first sample of every sequence, lane by lane (each lane counts its own finished sequences)

@@ -28,6 +28,106 @@ N_SAMPLES = 480000
 FRAMES_PER_SECOND = 100
 TIME_PRECISION = 0.02  # seconds per timestamp token
 INPUT_STRIDE = 2       # mel frames per encoder position
+CROSS_PATHS = {0: "kv16", 1: "kv_stream", 2: "xa_stream"}
+
+
+class WindowLoop:
+    """Host half of openai-whisper's `transcribe()` for ONE clip [UPSTREAM-RECALL: whisper/transcribe.py, main loop]: which 30 s window
+    is decoded next and with which prompt, and what a decoded window adds to the segments / tokens / `text` -- the only key the
+    reference reads (back/api.py:1103, 1447, 1488).  No GPU state: `WhisperModel.transcribe_batch` owns the device work and calls
+    `next_window()` / `advance()`; tests/test_transcribe_loop_cpu.py drives the same object with scripted decode results against
+    oracle/whisper_transcribe_ref.py.
+
+    Deviation: with `word_timestamps=True` (back/api.py:1435, 1477) upstream aligns words by cross-attention DTW
+    and, when a window does not end on a single timestamp, moves `seek` to the end of the last aligned word instead of the last
+    timestamp token.  The DTW (K11) is not built -- its words are never read by the reference -- so `seek` keeps the timestamp-token
+    rule; only audio that needs more than one window (longer than 30 s, or a window that ends inside an unfinished segment) can see it."""
+
+    def __init__(self, rules: DecodeRules, tokenizer, content_frames: int, initial_prompt: Optional[str], n_text_ctx: int,
+                 condition_on_previous_text: bool = True, no_speech_threshold: Optional[float] = 0.6,
+                 logprob_threshold: Optional[float] = -1.0):
+        self.rules, self.tokenizer, self.n_text_ctx = rules, tokenizer, int(n_text_ctx)
+        self.content = int(content_frames)
+        self.condition, self.no_speech_threshold, self.logprob_threshold = condition_on_previous_text, no_speech_threshold, logprob_threshold
+        ipt = tokenizer.encode(" " + initial_prompt.strip()) if initial_prompt else []
+        self.seek, self.all_tokens, self.n_init, self.reset = 0, list(ipt), len(ipt), 0
+        self.segments: List[dict] = []
+        self.seeks: List[int] = []
+
+    def active(self) -> bool:
+        return self.seek < self.content
+
+    def prompt_tokens(self) -> List[int]:
+        """decode_options["prompt"] = all_tokens[prompt_reset_since:]"""
+        return self.all_tokens[self.reset:]
+
+    def initial_tokens(self) -> List[int]:
+        """decoding.py::_get_initial_tokens: [sot_prev] + prompt[-(n_ctx // 2 - 1):] + [sot]."""
+        p = self.prompt_tokens()
+        toks: List[int] = []
+        if len(p):
+            toks = [self.rules.sot_prev] + list(p)[-(self.n_text_ctx // 2 - 1):]
+        return toks + [self.rules.sot]
+
+    def advance(self, r: dict, temperature: float = 0.0) -> None:
+        """One decoded window (r: tokens before eot, avg_logprob, no_speech_prob) -> segments, tokens, the next seek."""
+        tsb, eot = self.rules.timestamp_begin, self.rules.eot
+        seek = self.seek
+        self.seeks.append(seek)
+        segment_size = min(N_FRAMES, self.content - seek)
+        time_offset = seek * HOP / SAMPLE_RATE
+        segment_duration = segment_size * HOP / SAMPLE_RATE
+        tokens = list(r["tokens"])
+        if self.no_speech_threshold is not None:
+            skip = r["no_speech_prob"] > self.no_speech_threshold
+            if self.logprob_threshold is not None and r["avg_logprob"] > self.logprob_threshold:
+                skip = False
+            if skip:
+                self.seek = seek + segment_size
+                return
+        is_ts = [t >= tsb for t in tokens]
+        single_ts_ending = is_ts[-2:] == [False, True]
+        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
+        new_segments = []
+
+        def add(start, end, toks):
+            new_segments.append(dict(seek=seek, start=start, end=end, tokens=list(toks),
+                                     text=self.tokenizer.decode([t for t in toks if t < eot])))
+
+        if consecutive:
+            slices = list(consecutive)
+            if single_ts_ending:
+                slices.append(len(tokens))
+            last = 0
+            for cur in slices:
+                sl = tokens[last:cur]
+                add(time_offset + (sl[0] - tsb) * TIME_PRECISION, time_offset + (sl[-1] - tsb) * TIME_PRECISION, sl)
+                last = cur
+            if single_ts_ending:
+                self.seek = seek + segment_size
+            else:
+                self.seek = seek + (tokens[last - 1] - tsb) * INPUT_STRIDE
+        else:
+            duration = segment_duration
+            ts = [t for t in tokens if t >= tsb]
+            if ts and ts[-1] != tsb:
+                duration = (ts[-1] - tsb) * TIME_PRECISION
+            add(time_offset, time_offset + duration, tokens)
+            self.seek = seek + segment_size
+        for s in new_segments:
+            # "if a segment is instantaneous or does not contain text, clear it": its tokens do not reach the prompt or the text
+            if s["start"] == s["end"] or s["text"].strip() == "":
+                s["text"], s["tokens"] = "", []
+            self.segments.append(s)
+            self.all_tokens.extend(s["tokens"])
+        if not self.condition or temperature > 0.5:      # "do not feed the prompt tokens if a high temperature was used"
+            self.reset = len(self.all_tokens)
+        if self.seek <= seek:  # cannot happen under ApplyTimestampRules (a closing timestamp is > its opening one); never loop forever
+            self.seek = seek + segment_size
+
+    def result(self) -> dict:
+        text_tokens = self.all_tokens[self.n_init:]
+        return dict(text=self.tokenizer.decode(text_tokens), segments=self.segments, language="en", tokens=list(text_tokens))
 
 
 class WhisperModel:
@@ -51,6 +151,7 @@ class WhisperModel:
         self.handle = h
         self.max_audio_seconds = float(max_audio_seconds)
         self.sample_seed, self._sample_calls = 0, 0     # temperature > 0: Philox seed and per-call counter
+        self.last_cross_path = None
         self.ctx.check(self.lib.ccx_whisper_set_max_audio(self.handle, self.max_audio_seconds), "ccx_whisper_set_max_audio")
         # log-mel / encoder workspaces of another instance (kept alive here): only for instances whose log_mel / encode calls
         # are ordered on one stream, as in BatchPipeline.run_pinned_pipelined (include/ccx.h)
@@ -171,8 +272,11 @@ class WhisperModel:
             self.handle, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), mp, B, sample_len, float(temperature),
             int(seed) & 0xFFFFFFFFFFFFFFFF, toks.ctypes.data_as(i32p), ntok.ctypes.data_as(i32p), slp.ctypes.data_as(fp),
             nsp.ctypes.data_as(fp), _lib.current_stream_ptr()), "ccx_whisper_decode")
+        # which cross-attention formulation the decode ran (include/ccx.h: ccx_whisper_last_cross_path), kept in every record
+        self.last_cross_path = CROSS_PATHS.get(int(self.lib.ccx_whisper_last_cross_path(self.handle)), "unknown")
         return [dict(tokens=toks[b, :ntok[b]].tolist(), sum_logprob=float(slp[b]),
-                     avg_logprob=float(slp[b]) / (int(ntok[b]) + 1), no_speech_prob=float(nsp[b])) for b in range(B)]
+                     avg_logprob=float(slp[b]) / (int(ntok[b]) + 1), no_speech_prob=float(nsp[b]),
+                     cross_path=self.last_cross_path) for b in range(B)]
 
     # ------------------------------------------------------------------ transcribe (reference call surface)
     def initial_tokens(self, prompt_tokens: Sequence[int]) -> List[int]:
@@ -203,95 +307,47 @@ class WhisperModel:
         temperature = float(temperature)
         n = len(audios)
         initial_prompts = list(initial_prompts) if initial_prompts is not None else [None] * n
-        clips = []
-        for a in audios:
-            a = a.detach().to("cpu").numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-            clips.append(np.ascontiguousarray(a.reshape(-1), dtype=np.float32))
-        state = []
-        for i in range(n):
-            ip = initial_prompts[i]
-            ipt = self.tokenizer.encode(" " + ip.strip()) if ip else []
-            state.append(dict(seek=0, all_tokens=list(ipt), n_init=len(ipt), reset=0, segments=[],
-                              content=len(clips[i]) // HOP))
-        stride = max(max((len(c) for c in clips), default=1), 1)
+        # device tensors (the processor's crops) stay on the device; host arrays go up in one transfer
+        on_dev = n > 0 and all(isinstance(a, torch.Tensor) and a.is_cuda for a in audios)
+        if on_dev:
+            clips = [a.detach().reshape(-1) for a in audios]
+            lens = [int(c.numel()) for c in clips]
+        else:
+            clips = []
+            for a in audios:
+                a = a.detach().to("cpu").numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+                clips.append(np.ascontiguousarray(a.reshape(-1), dtype=np.float32))
+            lens = [len(c) for c in clips]
+        state = [WindowLoop(self.rules, self.tokenizer, lens[i] // HOP, initial_prompts[i], self.dims.n_text_ctx,
+                            condition_on_previous_text, no_speech_threshold, logprob_threshold) for i in range(n)]
+        stride = max(max(lens, default=1), 1)
         if stride > self.max_audio_seconds * SAMPLE_RATE:
             raise _lib.CcxError(f"clip of {stride / SAMPLE_RATE:.1f} s exceeds max_audio_seconds={self.max_audio_seconds}")
         # clips stay resident on the GPU for all windows
-        host = np.zeros((n, stride), dtype=np.float32)
-        for i, c in enumerate(clips):
-            host[i, :len(c)] = c
-        dev_audio = torch.from_numpy(host).to(self.device)
+        if on_dev:
+            dev_audio = torch.zeros(n, stride, device=self.device, dtype=torch.float32)
+            for i, c in enumerate(clips):
+                dev_audio[i, :lens[i]] = c.to(self.device, torch.float32)
+        else:
+            host = np.zeros((n, stride), dtype=np.float32)
+            for i, c in enumerate(clips):
+                host[i, :lens[i]] = c
+            dev_audio = torch.from_numpy(host).to(self.device)
         while True:
-            active = [i for i in range(n) if state[i]["seek"] < state[i]["content"]]
+            active = [i for i in range(n) if state[i].active()]
             if not active:
                 break
             for c0 in range(0, len(active), self.max_batch):
                 grp = active[c0:c0 + self.max_batch]
-                idx = torch.tensor(grp, device=self.device)
-                a = dev_audio.index_select(0, idx).contiguous()
-                self.log_mel(a, [len(clips[i]) for i in grp], [state[i]["seek"] for i in grp])
+                if len(grp) == n:
+                    a = dev_audio
+                else:
+                    a = dev_audio.index_select(0, torch.tensor(grp, device=self.device)).contiguous()
+                self.log_mel(a, [lens[i] for i in grp], [state[i].seek for i in grp])
                 self.encode(len(grp))
-                prompts = [self.initial_tokens(state[i]["all_tokens"][state[i]["reset"]:]) for i in grp]
+                prompts = [state[i].initial_tokens() for i in grp]
                 self._sample_calls += 1
                 results = self.decode(prompts, temperature=temperature, seed=(int(self.sample_seed) << 32) + self._sample_calls)
                 for i, r in zip(grp, results):
-                    self._advance(state[i], r, condition_on_previous_text, no_speech_threshold, logprob_threshold)
-        out = []
-        for i in range(n):
-            st = state[i]
-            text_tokens = st["all_tokens"][st["n_init"]:]
-            out.append(dict(text=self.tokenizer.decode(text_tokens), segments=st["segments"], language="en",
-                            tokens=[t for t in text_tokens]))
-        return out
-
-    def _advance(self, st: dict, r: dict, condition_on_previous_text: bool, no_speech_threshold, logprob_threshold):
-        """Window bookkeeping of transcribe.py's main loop for one decoded window."""
-        tsb, eot = self.rules.timestamp_begin, self.rules.eot
-        seek = st["seek"]
-        segment_size = min(N_FRAMES, st["content"] - seek)
-        time_offset = seek * HOP / SAMPLE_RATE
-        segment_duration = segment_size * HOP / SAMPLE_RATE
-        tokens = list(r["tokens"])
-        if no_speech_threshold is not None:
-            skip = r["no_speech_prob"] > no_speech_threshold
-            if logprob_threshold is not None and r["avg_logprob"] > logprob_threshold:
-                skip = False
-            if skip:
-                st["seek"] = seek + segment_size
-                return
-        is_ts = [t >= tsb for t in tokens]
-        single_ts_ending = is_ts[-2:] == [False, True]
-        consecutive = [i + 1 for i in range(len(tokens) - 1) if is_ts[i] and is_ts[i + 1]]
-        new_segments = []
-
-        def add(start, end, toks):
-            new_segments.append(dict(seek=seek, start=start, end=end, tokens=list(toks),
-                                     text=self.tokenizer.decode([t for t in toks if t < eot])))
-
-        if consecutive:
-            slices = list(consecutive)
-            if single_ts_ending:
-                slices.append(len(tokens))
-            last = 0
-            for cur in slices:
-                sl = tokens[last:cur]
-                add(time_offset + (sl[0] - tsb) * TIME_PRECISION, time_offset + (sl[-1] - tsb) * TIME_PRECISION, sl)
-                last = cur
-            if single_ts_ending:
-                st["seek"] = seek + segment_size
-            else:
-                st["seek"] = seek + (tokens[last - 1] - tsb) * INPUT_STRIDE
-        else:
-            duration = segment_duration
-            ts = [t for t in tokens if t >= tsb]
-            if ts and ts[-1] != tsb:
-                duration = (ts[-1] - tsb) * TIME_PRECISION
-            add(time_offset, time_offset + duration, tokens)
-            st["seek"] = seek + segment_size
-        for s in new_segments:
-            st["segments"].append(s)
-            st["all_tokens"].extend(s["tokens"])
-        if not condition_on_previous_text:
-            st["reset"] = len(st["all_tokens"])
-        if st["seek"] <= seek:  # never loop forever on a degenerate timestamp
-            st["seek"] = seek + segment_size
+                    state[i].advance(r, temperature)
+        return [st.result() for st in state]

@@ -175,6 +175,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
                        int sample_len, float temperature, uint64_t seed, int32_t* tokens_out, int32_t* n_tokens_out,
                        float* sum_logprob_out, float* no_speech_prob_out, void* stream);
 
+/* Which cross-attention formulation the last ccx_whisper_decode of this instance ran (measurement / test records; the reference has one
+ * formulation, MultiHeadAttention.forward(x, xa) behind back/api.py:1286-1292): 0 = "kv16" (per-layer K / V caches, split-KV kernels,
+ * <= 16 sequences), 1 = "kv_stream" (per-layer K / V caches, dec_cross_stream_kernel, 17 - 80 sequences), 2 = "xa_stream" (one pass over
+ * the encoder output per layer, csrc/cross_x.hip, more than 80 sequences); -1 before the first decode. */
+int ccx_whisper_last_cross_path(ccx_whisper* w);
+
 /* Batch-driver helper with no counterpart in the reference (it decodes one window at a time, back/api.py:1286): picks, once, the
  * internal streams on which the lanes of a large decode batch will run beside `stream` (HIP maps streams onto a few hardware
  * queues; the choice is made by a short timing probe, which must not be disturbed by other work on the GPU).  Call it on an
