@@ -8,9 +8,9 @@ the loop strides by 256, so only decodes past position 64 use waves 1-3 and only
 positional embedding, ApplyTimestampRules over long histories and the n_text_ctx edge are exercised by nothing shorter either.
 
 Every GPU token is walked through the oracle's KV-cached decoder (the arithmetic of `decoder_logits`, one token per call) under
-teacher forcing: it must be an eps-argmax of the oracle's filtered logits (eps 0.02 at mini dims, 0.03 at full small.en size -- 2.5 x the worst shortfall measured, 7.9e-3 / 1.1e-2; the short-decode tests use 0.05 / 0.08 --,
-equal to the argmax where the oracle's margin exceeds 2 eps, and the summed log-probability and
-the no-speech probability must agree.  Paths: the split-KV kernels of <= 16 sequences ("kv16"), the lean K / V stream of 17 - 80
+teacher forcing: it must be an eps-argmax of the oracle's filtered logits (eps 0.02 at mini dims, 0.03 at full small.en size: 2.5 x
+the worst shortfall measured, 7.9e-3 / 1.1e-2; the short-decode tests use 0.05 / 0.08), equal to the argmax where the oracle's margin
+exceeds 2 eps, and the summed log-probability and the no-speech probability must agree.  Paths: the split-KV kernels of <= 16 sequences ("kv16"), the lean K / V stream of 17 - 80
 sequences ("kv_stream", the default of that range) and the cross attention against the encoder output ("xa_stream", > 80
 sequences and every group of bench.py).
 """
