@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -59,6 +60,21 @@ struct ccx_prof_scope {
     active = true;
   }
   ~ccx_prof_scope() { if (active) hipEventRecord(stop, stream); }
+};
+
+// One-time opt-in of a kernel to more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), PER DEVICE and safe
+// for the two host threads that may drive one context (BatchPipeline.run_pinned_pipelined): one bit per device in an atomic, the
+// call itself is idempotent, so two threads racing to be first both make it and both succeed.  A `static ccx_lds_optin` lives next to
+// each launcher (one per kernel instantiation).
+struct ccx_lds_optin {
+  std::atomic<unsigned long long> done{0};
+  hipError_t ensure(int device, const void* fn, int bytes = 160 * 1024) {
+    const unsigned long long bit = 1ull << (device & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
 };
 
 // Set ctx error text and return the code (host side).

@@ -460,13 +460,14 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   // prompt prefill (rows_per_seq consecutive rows per sequence): four rows of a sequence share one pass over its xa
   // (CCX_XS_PREFILL_ROWS=1: one row per block, as the decode steps)
   static const int pf_rows = [] { const char* e = getenv("CCX_XS_PREFILL_ROWS"); return e ? atoi(e) : 4; }();
+  CCX_REQUIRE(ctx, pf_rows == 1 || pf_rows == 4, "xs cross attention: CCX_XS_PREFILL_ROWS=%d unsupported (1 or 4 rows per block)", pf_rows);
+  // rows of one sequence per block need the row -> sequence map (without it the kernel would take its row index as the sequence
+  // and read xa beyond the encoded windows)
+  CCX_REQUIRE(ctx, p.rows_per_seq <= 1 || p.row_seq != nullptr, "xs cross attention: rows_per_seq = %d needs row_seq", p.rows_per_seq);
   const bool multi = p.rows_per_seq > 1 && pf_rows == 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_xs_stream_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static ccx_lds_optin optin1, optin4;       // per device, race-free (ccx_common.h)
+  CCX_HIP(ctx, optin1.ensure(ctx->device, (const void*)dec_xs_stream_kernel<D, 1>));
+  CCX_HIP(ctx, optin4.ensure(ctx->device, (const void*)dec_xs_stream_kernel<D, 4>));
   CCX_REQUIRE(ctx, lds_pad >= 0 && G::LDS + lds_pad <= 160 * 1024, "xs cross attention: LDS claim %d too large", lds_pad);
   CCX_REQUIRE(ctx, p.rows_per_seq <= 1 || p.rows % p.rows_per_seq == 0, "xs cross attention: %d rows are not a multiple of %d rows per sequence", p.rows, p.rows_per_seq);
   const dim3 small_grid(p.H, ccx_cdiv(p.rows, 16));

@@ -465,12 +465,8 @@ static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ks
   size_t lds = act_bytes + red_bytes;
   CCX_REQUIRE(ctx, lds <= 160 * 1024, "dec_linear: LDS %zu too large", lds);
   CCX_REQUIRE(ctx, ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), 4) <= KMAX, "dec_linear: K=%d / split %d exceeds the prefetch depth %d", p.K, ksplit, KMAX);
-  static size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = 160 * 1024;
-  }
+  static ccx_lds_optin optin;
+  if (lds > 64 * 1024) CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI>));
   dim3 grid(ccx_cdiv(p.N, BN), ccx_cdiv(p.M, MROWS), ksplit);
   {
     // weight-streaming GEMV: algorithmic bytes = the weight matrix once (+ small activations)
@@ -1314,11 +1310,8 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
       const int pad = p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0;
 #define CCX_CROSS_STREAM_LAUNCH(F, ...)                                                                                      \
   do {                                                                                                                       \
-    static bool attr_ = false;                                                                                               \
-    if (!attr_) {                                                                                                            \
-      CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_cross_stream_kernel<F, __VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
-      attr_ = true;                                                                                                          \
-    }                                                                                                                        \
+    static ccx_lds_optin optin_;                                                                                             \
+    CCX_HIP(ctx, optin_.ensure(ctx->device, (const void*)dec_cross_stream_kernel<F, __VA_ARGS__>, 128 * 1024));              \
     hipLaunchKernelGGL((dec_cross_stream_kernel<F, __VA_ARGS__>), grid, dim3(256), pad, stream, p);                         \
   } while (0)
       if (final_out) {
@@ -1329,11 +1322,8 @@ int ccx_launch_dec_attention(ccx_ctx* ctx, const DecAttnParams& p, int B, int ns
 #undef CCX_CROSS_STREAM_LAUNCH
     } else if (final_out) hipLaunchKernelGGL(dec_attention_kernel<true>, grid, dim3(256), 0, stream, p);
     else {
-      static bool attr_set = false;
-      if (p.lds_pad > 0 && !attr_set) {   // static + dynamic LDS beyond 64 KB needs the opt-in
-        CCX_HIP(ctx, hipFuncSetAttribute((const void*)dec_attention_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-      }
+      static ccx_lds_optin optin;
+      if (p.lds_pad > 0) CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)dec_attention_kernel<false>, 128 * 1024));   // static + dynamic LDS beyond 64 KB
       hipLaunchKernelGGL(dec_attention_kernel<false>, grid, dim3(256), p.lds_pad > 0 ? (p.lds_pad < 128 * 1024 ? p.lds_pad : 128 * 1024) : 0, stream, p);
     }
   }

@@ -705,11 +705,8 @@ static int launch_epi_geo(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream)
   constexpr int TBM = WM * MT * 16, TBN = WN * 64;
   constexpr int LDS = 2 * (TBM + TBN) * 128;
   const int tiles = ccx_cdiv(p.M, TBM) * ccx_cdiv(p.N, TBN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<EPI, WM, WN, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  static ccx_lds_optin optin;
+  CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)gemm_bf16_nt_kernel<EPI, WM, WN, MT>, LDS));
   {
     // algorithmic work: 2*M*N*K flops; bytes = A + W read once + output written once
     const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;  // output element size
@@ -737,11 +734,8 @@ template <int EPI>
 static int launch_phased(ccx_ctx* ctx, const GemmParams& p, hipStream_t stream) {
   constexpr int LDS = 131072;
   const int tiles = ccx_cdiv(p.M, 256) * ccx_cdiv(p.N, 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    CCX_HIP(ctx, hipFuncSetAttribute((const void*)gemm_bf16_phased_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  static ccx_lds_optin optin;
+  CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)gemm_bf16_phased_kernel<EPI>, LDS));
   {
     const double obytes = (EPI == EPI_F32 || EPI == EPI_F32_RESID || EPI == EPI_F32_GELU_POS) ? 4.0 : 2.0;
     const double kt = (double)p.K * (p.ntaps > 1 ? p.ntaps : 1);

@@ -861,11 +861,8 @@ int run_block(ccx_sepformer* s, const SepBlock& B, const float* x, const float* 
     }
     {
       // LayerNorm 2 + Linear-ReLU-Linear + residual in one kernel (see sep_ffn_kernel)
-      static bool attr_set = false;
-      if (!attr_set) {
-        CCX_HIP(ctx, hipFuncSetAttribute((const void*)sep_ffn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS));
-        attr_set = true;
-      }
+      static ccx_lds_optin optin;
+      CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)sep_ffn_kernel, FF_LDS));
       ccx_prof_scope ps(ctx, st, "sep_ffn_kernel", 4.0 * n_tok * (double)D * F, 2.0 * n_tok * D * 4.0 + 4.0 * D * F);
       hipLaunchKernelGGL(sep_ffn_kernel, dim3(ccx_cdiv(n_tok, FF_TOK)), dim3(512), FF_LDS, st, h, L.ln2_g, L.ln2_b, L.W1, L.b1, L.W2, L.b2,
                          n_tok, F, 1e-6f);

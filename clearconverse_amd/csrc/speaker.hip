@@ -646,11 +646,8 @@ int run_sincnet(ccx_speaker* s, const float* wav, const Plan& P, hipStream_t st)
   int maxp = 0;
   for (int i = 0; i < P.n; i++) maxp = P.f1[i] > maxp ? P.f1[i] : maxp;
   {
-    static bool attr_set = false;
-    if (!attr_set) {
-      CCX_HIP(ctx, hipFuncSetAttribute((const void*)sinc_conv_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SM_LDS));
-      attr_set = true;
-    }
+    static ccx_lds_optin optin;
+    CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)sinc_conv_pool_kernel, SM_LDS));
     const int chunks = ccx_cdiv(maxp, SM_FRAMES);
     const long items = (long)chunks * P.n;
     long positions = 0;

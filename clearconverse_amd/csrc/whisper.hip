@@ -7,6 +7,7 @@
 // model.py / decoding.py [UPSTREAM-RECALL -- not vendored in the reference]; the CPU restatement
 // the tests compare against is oracle/whisper_ref.py.
 #include <array>
+#include <atomic>
 #include <map>
 #include <chrono>
 #include <math.h>
@@ -75,6 +76,7 @@ struct ccx_whisper {
   ccx_whisper* scratch_donor = nullptr;   // ccx_whisper_share_encoder_scratch: log-mel / encoder workspaces of another instance
   int scratch_takers = 0;                 // instances that borrowed THIS instance's workspaces and are still alive
   bool destroy_pending = false;           // ccx_whisper_destroy was called while takers were alive: freed with the last taker
+  std::atomic<ccx_whisper*> scratch_owner{nullptr};   // (donor) instance whose staged log-mel waits for its encode: a shared group has ONE user between logmel and encode
   hipEvent_t scratch_free = nullptr;      // (donor) recorded at the end of every encode of the group; every log-mel / set_mel of the
                                           // group waits for it, so that users of the shared workspaces are ordered on ANY streams
   std::map<std::string, HostTensor> staged;
@@ -332,6 +334,8 @@ void ccx_whisper_destroy(ccx_whisper* w) {
   }
   if (ccx_whisper* dn = w->scratch_donor) {
     w->scratch_donor = nullptr;
+    ccx_whisper* me = w;
+    dn->scratch_owner.compare_exchange_strong(me, nullptr);     // staged windows of a destroyed instance bind nobody
     if (--dn->scratch_takers == 0 && dn->destroy_pending) ccx_whisper_destroy(dn);
   }
   if (w->scratch_free) hipEventDestroy(w->scratch_free);
@@ -647,15 +651,27 @@ int ccx_whisper_finalize(ccx_whisper* w) {
 }
 
 // Shared log-mel / encoder workspaces (ccx_whisper_share_encoder_scratch): every user waits for the end of the group's previous
-// encode before it writes them, on whatever stream it runs (a no-op when all users share one stream).
+// encode before it writes them, on whatever stream it runs (a no-op when all users share one stream).  The event only orders a
+// logmel behind the previous ENCODE: between an instance's logmel / set_mel and its encode the workspaces hold its staged windows, so
+// the host must issue that pair back to back -- enforced here: another instance's logmel in between is refused (include/ccx.h).
 static int scratch_acquire(ccx_whisper* w, hipStream_t stream) {
   ccx_whisper* root = w->scratch_donor ? w->scratch_donor : w;
-  if (root->scratch_free) CCX_HIP(w->ctx, hipStreamWaitEvent(stream, root->scratch_free, 0));
+  if (root->scratch_free) {
+    ccx_whisper* owner = root->scratch_owner.load(std::memory_order_acquire);
+    CCX_REQUIRE(w->ctx, owner == nullptr || owner == w,
+                "whisper: the shared encoder workspaces hold another instance's staged windows -- issue its ccx_whisper_encode before this logmel / set_mel");
+    root->scratch_owner.store(w, std::memory_order_release);
+    CCX_HIP(w->ctx, hipStreamWaitEvent(stream, root->scratch_free, 0));
+  }
   return CCX_OK;
 }
 static int scratch_release(ccx_whisper* w, hipStream_t stream) {
   ccx_whisper* root = w->scratch_donor ? w->scratch_donor : w;
-  if (root->scratch_free) CCX_HIP(w->ctx, hipEventRecord(root->scratch_free, stream));
+  if (root->scratch_free) {
+    CCX_HIP(w->ctx, hipEventRecord(root->scratch_free, stream));
+    ccx_whisper* me = w;
+    root->scratch_owner.compare_exchange_strong(me, nullptr, std::memory_order_acq_rel);
+  }
   return CCX_OK;
 }
 

@@ -80,9 +80,11 @@ def load_mono_16k(path_or_wave, device: Optional[torch.device] = None, ctx=None)
         x = x.mean(axis=0)
     if sr != SR:
         idx = device.index if isinstance(device, torch.device) and device.index is not None else 0
-        rs = _RESAMPLERS.get((sr, idx))
-        if rs is None:
-            rs = _RESAMPLERS[(sr, idx)] = SincResampler(sr, SR, device=idx, ctx=ctx)
+        # keyed by the context too, and an entry whose context was closed is rebuilt (Context.close() sets handle = None)
+        key = (sr, idx, id(ctx))
+        rs = _RESAMPLERS.get(key)
+        if rs is None or getattr(getattr(rs, "ctx", None), "handle", True) is None:
+            rs = _RESAMPLERS[key] = SincResampler(sr, SR, device=idx, ctx=ctx)
         return rs(torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)))     # K1 on the pipeline's device, stays resident
     return np.ascontiguousarray(x, dtype=np.float32)
 
@@ -303,7 +305,7 @@ def agglomerative_centroid(emb: np.ndarray, threshold: float, min_cluster_size: 
     if num_clusters is not None:
         Zi = Z.copy()
         Zi[:, 2] = np.arange(n - 1)                     # cut by merge index instead of by distance
-        best_it, best_n = n - 1 - num_clusters, len(large)
+        best_it, best_n = n - 1, 1                      # upstream's start: the last merge / one large cluster (the fallback when no cut fits)
         for it in np.argsort(np.abs(Z[:, 2] - threshold)):
             if Zi[it, 3] < big:                          # this merge cannot have changed the number of large clusters
                 continue

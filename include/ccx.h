@@ -130,8 +130,10 @@ int ccx_whisper_set_max_audio(ccx_whisper* w, double seconds);
  * instance's capacity) instead of allocating them.  They are only live between ccx_whisper_logmel / set_mel and the end of
  * ccx_whisper_encode.  Users of one group are ordered by the library: every logmel / set_mel waits (event) for the end of the
  * group's previous encode, on whatever streams they run -- so an instance may encode while ANOTHER instance of the group decodes
- * (the software-pipelined batch driver), but the host must issue logmel .. encode of one instance before the next instance's
- * logmel.  A donor destroyed while takers are alive is freed when its last taker is destroyed. */
+ * (the software-pipelined batch driver), but the host must issue logmel / set_mel .. encode of one instance as an UNINTERRUPTED pair:
+ * the event orders a logmel behind the group's previous encode only, and between an instance's logmel and its encode the workspaces
+ * hold its staged windows.  Enforced: a logmel / set_mel of another instance of the group in between fails with CCX_ERR_ARG.
+ * A donor destroyed while takers are alive is freed when its last taker is destroyed. */
 int ccx_whisper_share_encoder_scratch(ccx_whisper* w, ccx_whisper* donor);
 /* Checks every tensor is present, builds the fused/bf16 device layouts, uploads. */
 int ccx_whisper_finalize(ccx_whisper* w);

@@ -232,8 +232,10 @@ def agglomerative_cluster(embeddings: np.ndarray, threshold: float, min_cluster_
         # stop by iteration index instead of by distance, going further and further away from the threshold
         _dend = np.copy(dendrogram)
         _dend[:, 2] = np.arange(num_embeddings - 1)
-        best_iteration = num_embeddings - 1 - num_clusters
-        best_num_large = num_large
+        # "best_iteration = num_embeddings - 1; best_num_large_clusters = 1": when no merge gives the wanted number of large clusters
+        # the fallback is the candidate closest to it, and if none beats ONE cluster, the last merge (everything in one cluster)
+        best_iteration = num_embeddings - 1
+        best_num_large = 1
         for iteration in np.argsort(np.abs(dendrogram[:, 2] - threshold)):
             if _dend[iteration, 3] < min_cluster_size:
                 continue

@@ -202,3 +202,34 @@ def test_vad_and_diarization_equal_the_oracle_pipelines_on_fake_nets():
             assert [l for _, _, l in got] == [l for _, _, l in want], (i, kw)
             assert [(s, e) for s, e, _ in got] == [(s, e) for s, e, _ in want], (i, kw)
             assert len(got) > 0
+
+
+def test_clustering_fallback_when_no_cut_gives_the_wanted_number_of_large_clusters():
+    """pyannote's AgglomerativeClustering.cluster starts its search from (best_iteration = n - 1, best_num_large_clusters = 1)
+    [UPSTREAM-RECALL, parity unpinned].  When the wanted number of clusters exceeds the largest number M of large clusters ANY cut of
+    the dendrogram has, the result is the cut closest to the threshold among those with M large clusters (every strictly better
+    candidate replaces the previous one), i.e. exactly M labels; with M = 1 everything collapses into one cluster.  M is found
+    here by scanning every cut, independently of either implementation."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from oracle import pyannote_pipeline_ref as O
+    rng = np.random.default_rng(11)
+    seen = {1: 0, 2: 0, 3: 0}
+    for trial in range(1200):
+        k = int(rng.integers(1, 4))
+        n = int(rng.integers(30, 70))
+        cents = rng.standard_normal((k, 16)) * 3.0
+        e = (cents[rng.integers(0, k, n)] + rng.standard_normal((n, 16)) * float(rng.choice([0.15, 1.0, 2.0]))).astype(np.float32)
+        mcs, target = 12, int(rng.choice([4, 6]))
+        big = min(mcs, max(1, round(0.1 * n)))
+        en = e.astype(np.float64) / np.linalg.norm(e.astype(np.float64), axis=-1, keepdims=True)
+        Z = linkage(en, method="centroid", metric="euclidean")
+        Zi = Z.copy(); Zi[:, 2] = np.arange(n - 1)
+        M = max(int((np.unique(fcluster(Zi, it, criterion="distance"), return_counts=True)[1] >= big).sum()) for it in range(n - 1))
+        if M >= target or M not in seen:
+            continue
+        seen[M] += 1
+        got = P.agglomerative_centroid(e, 0.7045654963945799, mcs, target, target, target)
+        want = O.agglomerative_cluster(e, 0.7045654963945799, mcs, target, target, target)
+        assert np.array_equal(got, want), trial
+        assert len(np.unique(got)) == M, (trial, M, np.unique(got))
+    assert seen[2] >= 3 and seen[3] >= 3, seen
