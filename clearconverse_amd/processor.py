@@ -78,6 +78,22 @@ class Config:  # reference back/api.py:112-135 -- same names, same defaults (dea
     secondary_diarization_threshold: float = 0.30
 
 
+@dataclass
+class _WhisperJob:
+    """One `whisper_model.transcribe` call of `process_file`, recorded by the first pass of the two-pass schedule.
+    prompt: the literal `initial_prompt`, or None when the prompt is the text of job `dep` (reference back/api.py:1425-1426,
+    1467-1468: `f"{previous_transcript.strip()} "` for the same speaker within 1.0 s)."""
+    audio: torch.Tensor
+    prompt: Optional[str]
+    dep: Optional[int]
+    word_timestamps: bool
+    condition: bool
+    wrap_errors: bool                       # overlap regions go through _transcribe, which re-raises as RuntimeError (reference 1294-1296)
+    done: Callable[[str], None]
+    failed: Optional[Callable[[Exception], None]] = None
+    text: Optional[str] = None
+
+
 def _tracks(annotation) -> List[Tuple[float, float, str]]:
     return [(seg.start, seg.end, label) for seg, _, label in annotation.itertracks(yield_label=True)]
 
@@ -310,7 +326,9 @@ class EnhancedAudioProcessor:
             raise
 
     def _process_overlap_segment(self, audio_segment: torch.Tensor, speaker_embeddings: Dict[str, torch.Tensor],
-                                 involved_speakers: List[str], seg_start: float, seg_end: float) -> List[Dict]:
+                                 involved_speakers: List[str], seg_start: float, seg_end: float,
+                                 jobs: Optional[List["_WhisperJob"]] = None) -> List[Dict]:
+        """reference 1066-1118.  `jobs` (two-pass schedule): the transcription of every region is recorded there instead of run."""
         out: List[Dict] = []
         for ns, ne, who in self._resegment_overlap(audio_segment, seg_start, seg_end, speaker_embeddings):
             piece = self._extract_segment(audio_segment, ns - seg_start, ne - seg_start)
@@ -327,9 +345,19 @@ class EnhancedAudioProcessor:
                     if sim > best_sim:
                         best, best_sim = src, sim
                 chosen = best if best is not None else piece
-                text = self._transcribe(chosen.squeeze().cpu().numpy(), initial_prompt=PROMPT_SINGLE,
-                                        temperature=self.config.temperature)["text"]
-                out.append({"audio": chosen, "transcription": text, "speaker_id": who, "confidence": best_sim})
+                rec = {"audio": chosen, "transcription": None, "speaker_id": who, "confidence": best_sim}
+                if jobs is None:
+                    rec["transcription"] = self._transcribe(chosen.squeeze().cpu().numpy(), initial_prompt=PROMPT_SINGLE,
+                                                            temperature=self.config.temperature)["text"]
+                else:
+                    # deferred (two-pass schedule): the fixed prompt makes this call independent of every other one.  A failing
+                    # call turns the record into the reference's marker segment, exactly as the except branch below does
+                    def failed(e, rec=rec, piece=piece):
+                        log.error("Error processing overlap subsegment: %s", e)
+                        rec.update({"audio": piece, "transcription": "[Processing error]", "confidence": 0.0, "error": str(e)})
+                    jobs.append(_WhisperJob(audio=chosen, prompt=PROMPT_SINGLE, dep=None, word_timestamps=False, condition=True,
+                                            wrap_errors=True, done=lambda t, rec=rec: rec.__setitem__("transcription", t), failed=failed))
+                out.append(rec)
             except Exception as e:  # noqa: BLE001 -- the reference keeps going with a marker segment
                 log.error("Error processing overlap subsegment: %s", e)
                 out.append({"audio": piece, "transcription": "[Processing error]", "speaker_id": who,
@@ -411,6 +439,65 @@ class EnhancedAudioProcessor:
             log.error("Error in whisper transcription: %s", e)
             raise RuntimeError(f"Transcription failed: {e}")
 
+    def _run_whisper_jobs(self, jobs: List[_WhisperJob]) -> None:
+        """Second pass of the two-pass schedule: run the recorded `transcribe` calls.
+
+        A model that only offers `transcribe` (the reference's duck-typed object, the scripted stubs of the glue fixtures) gets the
+        calls one by one in the recorded order -- exactly the reference's sequence.  A model with `transcribe_batch`
+        (clearconverse_amd.whisper.WhisperModel) gets them in dependency waves: wave 0 = every call with a literal prompt, wave
+        k + 1 = the calls whose prompt is the text of a wave-k call; the windows of a wave are encoded and decoded as ONE batch (one
+        decode chain of a few hundred steps for all of them instead of one chain per call).  `batch_whisper_calls = False` on the
+        processor (or CCX_BATCH_WHISPER_CALLS=0) keeps the serial order for such a model too."""
+        if not jobs:
+            return
+        cfg = self.config
+        wm = self.whisper_model
+        batched = (hasattr(wm, "transcribe_batch") and getattr(self, "batch_whisper_calls", True)
+                   and os.environ.get("CCX_BATCH_WHISPER_CALLS", "1") != "0")
+
+        def prompt_of(j: _WhisperJob) -> str:
+            return j.prompt if j.dep is None else f"{jobs[j.dep].text.strip()} "
+
+        def serial(j: _WhisperJob) -> None:
+            audio = j.audio.squeeze().cpu().numpy()
+            if j.wrap_errors:
+                try:
+                    j.text = self._transcribe(audio, initial_prompt=prompt_of(j), temperature=cfg.temperature)["text"]
+                except Exception as e:  # noqa: BLE001 -- overlap regions keep going with a marker segment (reference 1109-1117)
+                    j.text = ""
+                    j.failed(e)
+                    return
+            else:
+                j.text = wm.transcribe(audio, initial_prompt=prompt_of(j), word_timestamps=j.word_timestamps,
+                                       condition_on_previous_text=j.condition, temperature=cfg.temperature)["text"]
+            j.done(j.text)
+
+        if not batched:
+            for j in jobs:
+                serial(j)
+            return
+        level = []
+        for j in jobs:
+            level.append(0 if j.dep is None else level[j.dep] + 1)
+        for lv in range(max(level) + 1):
+            wave = [j for j, l in zip(jobs, level) if l == lv]
+            for cond in (True, False):
+                grp = [j for j in wave if j.condition == cond]
+                if not grp:
+                    continue
+                try:
+                    res = wm.transcribe_batch([j.audio for j in grp], [prompt_of(j) for j in grp], condition_on_previous_text=cond,
+                                              temperature=cfg.temperature)
+                except Exception as e:  # noqa: BLE001
+                    # attribute the failure call by call, with the reference's per-call error behaviour
+                    log.error("batched transcription failed (%s): running the %d calls one by one", e, len(grp))
+                    for j in grp:
+                        serial(j)
+                    continue
+                for j, r in zip(grp, res):
+                    j.text = r["text"]
+                    j.done(j.text)
+
     # ------------------------------------------------------------------ the hot path (A1)
     def process_file(self, file_path: str) -> Optional[Dict]:
         try:
@@ -458,7 +545,19 @@ class EnhancedAudioProcessor:
         tally = {"SPEAKER_A": 0, "SPEAKER_B": 0}
         prev_end: float = 0
         prev_spk: Optional[str] = None
-        prev_text = ""
+        # Two-pass schedule: this loop makes every decision of the reference's loop (back/api.py:1378-1530) in its order but RECORDS
+        # the Whisper calls instead of running them; `_run_whisper_jobs` then runs them -- one after the other in the recorded order
+        # for a duck-typed model that only has `transcribe` (the reference's own object), or, for a model with `transcribe_batch`,
+        # all calls whose prompt is known together.  No decision of the loop reads a transcript: the only use of the previous text
+        # is the NEXT call's prompt (same speaker within 1.0 s, 1425-1426 / 1467-1468), which is what `dep` records.
+        jobs: List[_WhisperJob] = []
+        overlap_pairs: List[Tuple[Dict, AudioSegment]] = []
+        prev_job: Optional[int] = None              # the job whose text is `previous_transcript`; None = "" (start, or after an overlap)
+
+        def record(crop, prompt, dep, seg: AudioSegment) -> int:
+            jobs.append(_WhisperJob(audio=crop, prompt=prompt, dep=dep, word_timestamps=True, condition=cfg.condition_on_previous_text,
+                                    wrap_errors=False, done=lambda t, seg=seg: setattr(seg, "transcription", t)))
+            return len(jobs) - 1
 
         for seg_start, seg_end, orig in segs:
             if (seg_end - seg_start) < cfg.min_segment_duration:
@@ -474,12 +573,14 @@ class EnhancedAudioProcessor:
             rapid = prev_spk is not None and prev_spk != orig and 0 < (seg_start - prev_end) < 0.5
 
             if in_overlap:
-                prev_spk, prev_text = None, ""
+                prev_spk, prev_job = None, None
                 mapped = {names.get(k, k): v for k, v in profiles.items()}
-                for r in self._process_overlap_segment(crop, mapped, [names.get(s, s) for s in involved], seg_start, seg_end):
-                    out.append(AudioSegment(start=seg_start, end=seg_end, speaker_id=r["speaker_id"], audio_tensor=r["audio"],
-                                            is_overlap=True, transcription=r["transcription"],
-                                            confidence=r.get("confidence", 0.5), metadata={"overlap_speakers": involved}))
+                for r in self._process_overlap_segment(crop, mapped, [names.get(s, s) for s in involved], seg_start, seg_end, jobs):
+                    seg = AudioSegment(start=seg_start, end=seg_end, speaker_id=r["speaker_id"], audio_tensor=r["audio"],
+                                       is_overlap=True, transcription=r["transcription"],
+                                       confidence=r.get("confidence", 0.5), metadata={"overlap_speakers": involved})
+                    out.append(seg)
+                    overlap_pairs.append((r, seg))      # a deferred transcription (or its failure) lands in the record first
                 prev_end = seg_end
                 continue
 
@@ -490,34 +591,36 @@ class EnhancedAudioProcessor:
                 if sim < cfg.secondary_diarization_threshold:
                     for ns, ne, nspk in self._secondary_diarization(crop, seg_start, seg_end):
                         sub = self._extract_segment(crop, ns - seg_start, ne - seg_start)
-                        prompt = PROMPT_COMPLETE
+                        prompt, dep = PROMPT_COMPLETE, None
                         if nspk == prev_spk and seg_start - prev_end < 1.0:
-                            prompt = f"{prev_text.strip()} "
+                            prompt, dep = None, prev_job                # f"{previous_transcript.strip()} " once job `dep` has run
                         if rapid:
-                            prompt = PROMPT_FAST
-                        text = self.whisper_model.transcribe(sub.squeeze().cpu().numpy(), initial_prompt=prompt, word_timestamps=True,
-                                                             condition_on_previous_text=cfg.condition_on_previous_text,
-                                                             temperature=cfg.temperature)["text"]
+                            prompt, dep = PROMPT_FAST, None
                         final = names.get(nspk, label)
-                        out.append(AudioSegment(start=seg_start + ns, end=seg_start + ne, speaker_id=final, audio_tensor=sub,
-                                                is_overlap=False, transcription=text, confidence=1.0,
-                                                metadata={"rapid_exchange": rapid}))
+                        seg = AudioSegment(start=seg_start + ns, end=seg_start + ne, speaker_id=final, audio_tensor=sub,
+                                           is_overlap=False, transcription=None, confidence=1.0,
+                                           metadata={"rapid_exchange": rapid})
+                        out.append(seg)
                         tally[final] = tally.get(final, 0) + 1
-                        prev_end, prev_spk, prev_text = seg_start + ne, nspk, text
+                        prev_job = record(sub, prompt, dep, seg)
+                        prev_end, prev_spk = seg_start + ne, nspk
                     continue
 
-            prompt = PROMPT_TWO_PEOPLE
+            prompt, dep = PROMPT_TWO_PEOPLE, None
             if orig == prev_spk and seg_start - prev_end < 1.0:
-                prompt = f"{prev_text.strip()} "
+                prompt, dep = None, prev_job
             if rapid:
-                prompt = PROMPT_FAST
-            text = self.whisper_model.transcribe(crop.squeeze().cpu().numpy(), initial_prompt=prompt, word_timestamps=True,
-                                                 condition_on_previous_text=cfg.condition_on_previous_text,
-                                                 temperature=cfg.temperature)["text"]
-            out.append(AudioSegment(start=seg_start, end=seg_end, speaker_id=label, audio_tensor=crop, is_overlap=False,
-                                    transcription=text, confidence=1.0, metadata={"rapid_exchange": rapid}))
+                prompt, dep = PROMPT_FAST, None
+            seg = AudioSegment(start=seg_start, end=seg_end, speaker_id=label, audio_tensor=crop, is_overlap=False,
+                               transcription=None, confidence=1.0, metadata={"rapid_exchange": rapid})
+            out.append(seg)
             tally[label] = tally.get(label, 0) + 1
-            prev_end, prev_spk, prev_text = seg_end, orig, text
+            prev_job = record(crop, prompt, dep, seg)
+            prev_end, prev_spk = seg_end, orig
+
+        self._run_whisper_jobs(jobs)
+        for rec, seg in overlap_pairs:
+            seg.transcription, seg.audio_tensor, seg.confidence = rec["transcription"], rec["audio"], rec.get("confidence", 0.5)
 
         out.sort(key=lambda s: s.start)
         meta = {"duration": duration, "speaker_a_segments": tally.get("SPEAKER_A", 0),

@@ -112,3 +112,84 @@ def test_extract_segment_edge_cases():
     assert p._extract_segment(a, 1.5, 9.0).shape == (1, 8000)          # clipped to the 2.0 s clip
     assert p._extract_segment(a, 1.0, 1.0).shape == (1, 100)           # invalid -> zeros(1,100), reference 855-858
     assert p._extract_embedding(torch.zeros(1, 7999)) is None          # < 0.5 s -> no embedding, reference 864-866
+
+
+class BatchStubWhisper:
+    """A whisper model that ALSO offers transcribe_batch (like clearconverse_amd.whisper.WhisperModel): the text is a function of the
+    call's audio length and prompt only, so the order of the calls cannot show in the results."""
+
+    def __init__(self):
+        self.calls, self.batches = [], []
+
+    @staticmethod
+    def _text(n, prompt):
+        import zlib
+        return f" utt{zlib.crc32(repr((n, prompt)).encode()) % 100000} n{n}."
+
+    def transcribe(self, audio, initial_prompt=None, word_timestamps=False, condition_on_previous_text=True, temperature=0.0, **kw):
+        n = int(np.asarray(audio).reshape(-1).shape[0])
+        self.calls.append(dict(n_samples=n, initial_prompt=initial_prompt, condition_on_previous_text=bool(condition_on_previous_text),
+                               temperature=float(temperature)))
+        return {"text": self._text(n, initial_prompt)}
+
+    def transcribe_batch(self, audios, initial_prompts=None, condition_on_previous_text=True, temperature=0.0, **kw):
+        self.batches.append(len(audios))
+        return [self.transcribe(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, initial_prompt=p,
+                                condition_on_previous_text=condition_on_previous_text, temperature=temperature)
+                for a, p in zip(audios, initial_prompts)]
+
+
+@pytest.mark.parametrize("name", sorted(PROCESS["scenarios"]))
+def test_two_pass_schedule_batched_equals_serial(name):
+    """The two-pass schedule of process_file: the Whisper calls recorded by the first pass, run in dependency waves through
+    transcribe_batch, give the segments, texts, prompts and transcript of the serial order (reference back/api.py:1378-1530) -- only
+    the ORDER of the calls differs.  Prompt-carrying calls (same speaker within 1.0 s: 1425-1426, 1467-1468) wait for their wave."""
+    sc = Scenario.from_json(PROCESS["scenarios"][name]["scenario"])
+    outs = []
+    for batched in (False, True):
+        p, diar_calls = _build(sc)
+        p.whisper_model = BatchStubWhisper()
+        p.batch_whisper_calls = batched
+        res = p.process_file("clip.wav")
+        outs.append((result_to_json(res, sorted(p.whisper_model.calls, key=repr), p.separator.calls, diar_calls),
+                     None if res is None else EnhancedAudioProcessor.format_transcript(res["segments"]), p.whisper_model))
+    (a, ta, wa), (b, tb, wb) = outs
+    _close(json.loads(json.dumps(b)), json.loads(json.dumps(a)), name)
+    assert ta == tb
+    assert wa.batches == [] and (len(wb.calls) == 0 or len(wb.batches) >= 1)
+    if name == "rapid_exchange_and_prompt_carry":
+        carried = [c for c in wb.calls if c["initial_prompt"].startswith("utt")]
+        assert len(carried) == 1 and wb.batches == [5, 1]                   # at least one dependent wave
+    if name == "two_speakers_one_overlap_30s":
+        assert wb.batches == [len(wb.calls)] and len(wb.calls) >= 4          # no prompt depends on a text: ONE batch
+
+
+def test_two_pass_schedule_overlap_failure_becomes_a_marker_segment():
+    """A failing transcription of an overlap region gives the reference's marker segment (back/api.py:1109-1117) in the batched
+    schedule too: the batch is re-run call by call, and the failing call alone is marked."""
+    sc = Scenario.from_json(PROCESS["scenarios"]["two_speakers_overlap_10s"]["scenario"])
+    p, _ = _build(sc)
+
+    class Failing(BatchStubWhisper):
+        def transcribe(self, audio, initial_prompt=None, **kw):
+            n = int(np.asarray(audio).reshape(-1).shape[0])
+            if initial_prompt == "This is a single speaker talking." and n == self.bad:
+                raise ValueError("scripted failure")
+            return super().transcribe(audio, initial_prompt=initial_prompt, **kw)
+
+        def transcribe_batch(self, audios, initial_prompts=None, **kw):
+            if any(int(a.numel()) == self.bad for a in audios):
+                raise RuntimeError("batch failed")
+            return super().transcribe_batch(audios, initial_prompts, **kw)
+    serial, _ = _build(sc)
+    serial.whisper_model = BatchStubWhisper()
+    serial.batch_whisper_calls = False
+    ref = serial.process_file("clip.wav")
+    overlap = [s_ for s_ in ref["segments"] if s_.is_overlap]
+    p.whisper_model = Failing()
+    p.whisper_model.bad = int(overlap[1].audio_tensor.shape[-1])
+    res = p.process_file("clip.wav")
+    marked = [s_ for s_ in res["segments"] if s_.transcription == "[Processing error]"]
+    assert len(marked) >= 1 and all(s_.confidence == 0.0 and s_.is_overlap for s_ in marked)
+    assert len(res["segments"]) == len(ref["segments"])
+    assert sum(s_.transcription != "[Processing error]" for s_ in res["segments"]) >= 1
