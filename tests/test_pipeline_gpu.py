@@ -90,6 +90,45 @@ def test_processor_run_on_wav_file(scripted_models, tmp_path, temperature):
     assert sr == 16000 and audio.shape == (1, 480000) and abs(float(audio.abs().max()) - 1.0) < 1e-4
 
 
+def test_two_pass_schedule_batched_whisper_calls_equal_the_serial_order(scripted_models, tmp_path, monkeypatch):
+    """process_file records its Whisper calls and runs them in dependency waves through WhisperModel.transcribe_batch (one decode
+    batch per wave; a prompt that carries the previous segment's text -- reference back/api.py:1425-1426, 1467-1468 -- waits for its
+    wave).  At temperature 0 the transcript, every segment's text, speaker, times and audio must be exactly those of the serial order
+    (batch_whisper_calls = False: one B = 1 decode per call, the reference's sequence): a window's tokens do not depend on its batch
+    mates (tests/test_whisper_gpu.py), so this holds bit for bit."""
+    from clearconverse_amd.processor import Config, EnhancedAudioProcessor
+    # two clips: the pinned 30 s schedule (no call depends on another: ONE wave) and a dialogue whose turns follow each other within
+    # a second (scripted segmentation weights fitted to clip 1: whatever they give on the second clip, both schedules must agree)
+    clips = [synthetic_clip(1, 30.0), np.concatenate([synthetic_clip(1, 30.0)[16000 * 18:16000 * 24], synthetic_clip(1, 30.0)[16000 * 18:16000 * 30]])]
+    for ci, clip in enumerate(clips):
+        path = str(tmp_path / f"clip{ci}.wav")
+        write_wav(path, clip)
+        outs = []
+        for batched in (False, True):
+            p = EnhancedAudioProcessor(Config(temperature=0.0, min_speakers=1 + (ci == 0), max_speakers=2), load_models_immediately=False,
+                                       model_loader=lambda cfg, dev: scripted_models)
+            p._initialize_models()
+            p.batch_whisper_calls = batched
+            calls = []
+            wm = scripted_models["whisper_model"]
+            orig = wm.transcribe_batch
+            monkeypatch.setattr(wm, "transcribe_batch", lambda audios, prompts=None, **kw: (calls.append(len(audios)), orig(audios, prompts, **kw))[1])
+            res = p.process_file(path)
+            monkeypatch.undo()
+            assert res is not None and len(res["segments"]) >= 1
+            outs.append((res, calls))
+        (a, ca), (b, cb) = outs
+        assert EnhancedAudioProcessor.format_transcript(a["segments"]) == EnhancedAudioProcessor.format_transcript(b["segments"]), ci
+        for x, y in zip(a["segments"], b["segments"]):
+            assert (x.start, x.end, x.speaker_id, x.is_overlap, x.transcription, x.confidence) == (y.start, y.end, y.speaker_id, y.is_overlap, y.transcription, y.confidence)
+            assert torch.equal(x.audio_tensor, y.audio_tensor)
+        n_calls = sum(ca)
+        assert all(c == 1 for c in ca) and sum(cb) == n_calls and len(cb) <= len(ca)       # WhisperModel.transcribe goes through transcribe_batch
+        if ci == 0:
+            assert len(cb) == 1 and cb[0] >= 4, cb                                        # the pinned schedule: one wave for all calls
+        print(f"clip {ci}: {n_calls} Whisper calls, serial {len(ca)} decodes, two-pass schedule {cb}")
+
+
 def test_pinned_batch_driver_counts(models):
     from clearconverse_amd.batch import BatchPipeline
     bp = BatchPipeline(models, whisper_group=16, sample_len=8)
