@@ -19,6 +19,9 @@ struct XsParams {
   const float* ln_g; const float* ln_b; float eps;
   const bf16_t* Wq;      // [D][D] row-major cross_attn.query.weight
   const float* bq;       // [D]
+  // LayerNorm-free chain (dec_xq_lnfree_kernel): the raw residual rows as bf16 + their per-tile statistics; Wq then holds gamma o Wq,
+  // bq the folded constant c, and q = rstd (xb Wq^T - mean ln_s) + c  (decoder.h, ACT_BF16_LN)
+  const bf16_t* xb; const float2* ln_stats; const float* ln_s;
   const bf16_t* WkT;     // [H][D][64]: WkT[h][f][d] = Wk[h*64 + d][f]   (cross_attn.key.weight re-laid per head)
   bf16_t* xq;            // [rows][H][D]: expanded queries
   float* part_o;         // [rows][XS_SPLIT][H][D]: unnormalised contexts of each key half (ccx_xs_part_o_elems)

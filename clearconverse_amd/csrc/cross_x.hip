@@ -166,6 +166,87 @@ __global__ __launch_bounds__(256) void dec_xq_fused_kernel(XsParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The expansion with the query projection of the LayerNorm-FREE chain: the producer of the residual stream (the self-attention output
+// projection, DEPI_RESOLVE in decoder.hip) left the resolved rows as bf16 and (sum, sum of squares) per 16-column tile; the LayerNorm
+// is applied algebraically, q = rstd (xb (gamma o Wq)^T - mean s) + c.  Block = (head, 16 rows): no resolve, no normalisation pass, the
+// rows go from global memory straight into the MFMA B operand.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void dec_xq_lnfree_kernel(XsParams p) {
+  constexpr int NKS = D / 32, FW = D / 4, NMT = FW / 16, RSQ = 2 * 64 + 16;
+  __shared__ __attribute__((aligned(16))) char q_s[16 * RSQ];
+  __shared__ float2 st_s[16];
+  const int h = blockIdx.x, r0 = blockIdx.y * 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  int row = r0 + n;
+  const bool live = row < p.rows;
+  if (!live) row = p.rows - 1;
+  // the head's slice of gamma o Wq: wave w -> rows h*64 + 16 w + n; and the 16 raw rows (B operand)
+  bf16x8 wq[NKS], xb[NKS];
+  {
+    const bf16_t* wsrc = p.Wq + (long)(h * 64 + wave * 16 + n) * D + g * 8;
+    const bf16_t* xsrc = p.xb + (long)row * D + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) wq[ks] = *(const bf16x8*)(wsrc + ks * 32);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ks++) xb[ks] = *(const bf16x8*)(xsrc + ks * 32);
+  }
+  // (mean, rstd) of the 16 rows: four threads per row, a quarter of the D / 16 tiles each, (q0 + q1) + (q2 + q3) -- the order of
+  // dec_linear_kernel<ACT_BF16_LN>
+  if (threadIdx.x < 64) {
+    const int r = threadIdx.x >> 2, qt = threadIdx.x & 3;
+    int m = r0 + r;
+    m = m < p.rows ? m : p.rows - 1;
+    constexpr int T4 = (D / 16) / 4;
+    const float2* sp = p.ln_stats + (long)m * (D / 16) + qt * T4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < T4; i++) {
+      const float2 v = sp[i];
+      s1 += v.x; s2 += v.y;
+    }
+    s1 += dpp_mov<CCX_DPP_QUAD_XOR1>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR1>(s2);
+    s1 += dpp_mov<CCX_DPP_QUAD_XOR2>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR2>(s2);
+    const float mean = s1 / (float)D;
+    const float var = fmaf(-mean, mean, s2 / (float)D);
+    if (qt == 0) st_s[r] = make_float2(mean, rsqrtf(fmaxf(var, 0.f) + p.eps));
+  }
+  // the expansion's weights and the folded constants fly under the MFMAs
+  const bf16_t* wbase = p.WkT + ((long)h * D + wave * FW + n) * 64 + g * 8;
+  bf16x8 wk[NMT][2];
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    wk[mt][0] = *(const bf16x8*)(wbase + (long)mt * 16 * 64);
+    wk[mt][1] = *(const bf16x8*)(wbase + (long)mt * 16 * 64 + 32);
+  }
+  const float4 cc = *(const float4*)(p.bq + h * 64 + wave * 16 + g * 4);
+  const float4 ss = *(const float4*)(p.ln_s + h * 64 + wave * 16 + g * 4);
+  f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < NKS; ks++) {
+    if (ks & 1) cb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks], xb[ks], cb, 0, 0, 0);
+    else ca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[ks], xb[ks], ca, 0, 0, 0);
+  }
+  __syncthreads();
+  {
+    const float2 ms = st_s[n];
+    const float v0 = fmaf(ms.y, fmaf(-ms.x, ss.x, ca[0] + cb[0]), cc.x), v1 = fmaf(ms.y, fmaf(-ms.x, ss.y, ca[1] + cb[1]), cc.y);
+    const float v2 = fmaf(ms.y, fmaf(-ms.x, ss.z, ca[2] + cb[2]), cc.z), v3 = fmaf(ms.y, fmaf(-ms.x, ss.w, ca[3] + cb[3]), cc.w);
+    *(u32x2*)(q_s + n * RSQ + (wave * 16 + g * 4) * 2) = (u32x2){pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+  }
+  __syncthreads();
+  const bf16x8 qb0 = *(const bf16x8*)(q_s + n * RSQ + g * 16), qb1 = *(const bf16x8*)(q_s + n * RSQ + 64 + g * 16);
+  bf16_t* dst = p.xq + ((long)row * p.H + h) * D + wave * FW + g * 4;
+#pragma unroll
+  for (int mt = 0; mt < NMT; mt++) {
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk[mt][0], qb0, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk[mt][1], qb1, c, 0, 0, 0);
+    if (live) *(u32x2*)(dst + mt * 16) = (u32x2){pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3])};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // out = ctx Wv^T + bv per head, ctx = the merged key-half partials of dec_xs_stream_kernel.  Block = (head, 16 rows): all 256
 // threads merge the head's contexts of the 16 rows into LDS as bf16 (ctx = (o0 w0 + o1 w1) / (l0 w0 + l1 w1), w_s = exp2(m_s - max m):
 // the flash-decoding merge, in a fixed order), then wave w owns the head's output features [16 w, 16 w + 16).
@@ -472,7 +553,11 @@ int launch_xs(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, p.rows_per_seq <= 1 || p.rows % p.rows_per_seq == 0, "xs cross attention: %d rows are not a multiple of %d rows per sequence", p.rows, p.rows_per_seq);
   const dim3 small_grid(p.H, ccx_cdiv(p.rows, 16));
   const double wbytes = (double)p.H * 64 * D * 2;
-  if (p.x) {
+  if (p.xb) {
+    ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xq_lnfree_kernel<768>" : "dec_xq_lnfree_kernel", 2.0 * p.rows * D * (double)D * 2,
+                      2.0 * wbytes + (double)p.rows * D * 2 + (double)p.rows * p.H * D * 2);
+    hipLaunchKernelGGL(dec_xq_lnfree_kernel<D>, small_grid, dim3(256), 0, stream, p);
+  } else if (p.x) {
     ccx_prof_scope ps(ctx, stream, D == 768 ? "dec_xq_fused_kernel<768>" : "dec_xq_fused_kernel", 2.0 * p.rows * D * (double)D * 2,
                       2.0 * wbytes + (double)p.rows * D * 4 * (1 + p.pend_n) + (double)p.rows * p.H * D * 2);
     hipLaunchKernelGGL(dec_xq_fused_kernel<D>, small_grid, dim3(256), 0, stream, p);
@@ -507,7 +592,8 @@ bool ccx_xs_supported(int D, int H) { return H >= 1 && H <= 16 && H * 64 == D &&
 
 int ccx_launch_xs_cross_attention(ccx_ctx* ctx, const XsParams& p, hipStream_t stream) {
   CCX_REQUIRE(ctx, ccx_xs_supported(p.D, p.H), "xs cross attention: width %d with %d heads is not instantiated", p.D, p.H);
-  CCX_REQUIRE(ctx, p.rows >= 1 && p.S >= 16 && (p.q || p.x) && p.WkT && p.xq && p.X && p.Wv && p.bv && p.out, "xs cross attention: bad arguments");
+  CCX_REQUIRE(ctx, p.rows >= 1 && p.S >= 16 && (p.q || p.x || p.xb) && p.WkT && p.xq && p.X && p.Wv && p.bv && p.out, "xs cross attention: bad arguments");
+  CCX_REQUIRE(ctx, !p.xb || (p.ln_stats && p.ln_s && p.Wq && p.bq), "xs cross attention: bad LayerNorm-free query arguments");
   CCX_REQUIRE(ctx, !p.x || (p.pend && p.ln_g && p.ln_b && p.Wq && p.bq && p.pend_n >= 0 && p.pend_n <= 4 && p.x_out != p.x), "xs cross attention: bad fused-query arguments");
   CCX_REQUIRE(ctx, p.part_o && p.part_ml, "xs cross attention: partial buffers missing");
   switch (p.D) {

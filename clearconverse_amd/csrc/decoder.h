@@ -2,8 +2,13 @@
 #pragma once
 #include "ccx_common.h"
 
-enum { ACT_LN = 0, ACT_BF16 = 1, ACT_COMBINE = 2 };
-enum { DEPI_BF16_GELU = 1, DEPI_PARTIAL = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4 };
+// ACT_BF16_LN: bf16 rows of the RAW (resolved, not normalised) residual stream + per-row LayerNorm statistics; the LayerNorm is applied
+// algebraically in the epilogue: LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + c with s_n = sum_k (gamma o W)_nk, c_n = sum_k beta_k W_nk + b_n
+// (the "LayerNorm-free" decode chain of the X-stream path, whisper.hip)
+enum { ACT_LN = 0, ACT_BF16 = 1, ACT_COMBINE = 2, ACT_BF16_LN = 3 };
+// DEPI_RESOLVE: the residual add done by the PRODUCER (no split-K slabs): x[m][n] += acc + bias in place (fp32), a bf16 copy of the new
+// row and, per 16-column tile of every row, (sum, sum of squares) -- the statistics the next ACT_BF16_LN consumer normalises with
+enum { DEPI_BF16_GELU = 1, DEPI_PARTIAL = 2, DEPI_F32 = 3, DEPI_SELF_QKV = 4, DEPI_RESOLVE = 5 };
 
 struct DecLinearParams {
   int M, N, K;
@@ -17,6 +22,10 @@ struct DecLinearParams {
   int ln_nt;                      // ACT_LN with more than 16 rows: 16-column tiles per block (4 / 6 / 8 / 12; see ccx_launch_dec_linear)
   const bf16_t* act; long lda;    // ACT_BF16: [M][K]
   const float* part_o; const float* part_ml; int nsplit;  // ACT_COMBINE: [M][H][nsplit][64], [M][H][nsplit][2]
+  // ACT_BF16_LN: statistics of the input rows [M][K / 16] (sum, sum of squares per 16-column tile), s [N]; `bias` holds c [N]
+  const float2* ln_stats; const float* ln_s;
+  // DEPI_RESOLVE: xres [M][N] f32 (read and written in place), xb [M][N] bf16, st_out [M][N / 16]
+  float* xres; bf16_t* xb; float2* st_out;
   // outputs (DEPI_PARTIAL: out[z][m][n] with stride pend_stride between the grid.z slices)
   void* out; long ldo;
   // DEPI_SELF_QKV: q -> out (f32 [M][K]), k/v -> caches [sequence][H][cache_T][64] at pos[m]; the sequence of row m is
@@ -29,6 +38,10 @@ int ccx_dec_linear_ksplit(int K, int epi);
 // out = bf16 LayerNorm(x + sum pend); if x_out != null also writes the resolved x there (must not alias x)
 int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, int pend_n, long pend_stride, const float* g,
                               const float* b, bf16_t* out, float* x_out, int M, int K, float eps, hipStream_t stream);
+
+// LayerNorm-free chain: x += sum pend (in place), xb = bf16(x), st = (sum, sum of squares) per 16-column tile of every row
+int ccx_launch_dec_resolve_stats(ccx_ctx* ctx, float* x, const float* pend, int pend_n, long pend_stride, bf16_t* xb, float2* st, int M,
+                                 int K, hipStream_t stream);
 
 struct DecAttnParams {
   const float* q;       // [B][H][64] f32

@@ -54,18 +54,23 @@ __global__ void dec_embed_kernel(const float* __restrict__ tok_emb, const float*
 // grid.z = K split, so 4.7 MB matrices spread over 192 blocks instead of 48) and the NEXT
 // LayerNorm prologue folds them in (x_eff = x_in + sum partials), block (0,*,0) writing x_eff to
 // the other residual buffer (ping-pong: no block may see a half-updated stream).
-template <int MT, int NT, int KMAX, int ACT, int EPI>
-__global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
+// NW waves per block split K (4; 12 for the K = 3072 second MLP linear of the LayerNorm-free chain, which must not use split-K slabs).
+template <int MT, int NT, int KMAX, int ACT, int EPI, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void dec_linear_kernel(DecLinearParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int MROWS = 16 * MT;
   constexpr int BN = 16 * NT;
+  constexpr int NTHR = 64 * NW;
+  constexpr bool BF16IN = (ACT == ACT_BF16 || ACT == ACT_BF16_LN);
+  static_assert(NW == 4 || ACT == ACT_BF16, "the LayerNorm / combine prologues are written for four waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * BN;
   const int m0 = blockIdx.y * MROWS;
   const int K = p.K;
   const int lds_ld = K + 8;  // bf16 elements per LDS activation row (ACT_LN / ACT_COMBINE only)
   bf16_t* act_s = (bf16_t*)smem;
-  float* red = (float*)(smem + ((ACT == ACT_BF16) ? 0 : ccx_align((size_t)MROWS * lds_ld * 2, 16)));
+  float* red = (float*)(smem + (BF16IN ? 0 : ccx_align((size_t)MROWS * lds_ld * 2, 16)));
+  float2* lnst = (float2*)(red + NW * NT * MT * 64 * 4);      // ACT_BF16_LN: (mean, rstd) of the block's rows
 
   const int l15 = lane & 15, h4 = lane >> 4;
   // K range of this block (grid.z split), then of this wave
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   const int per_z = (ksteps + gridDim.z - 1) / gridDim.z;
   const int kz0 = blockIdx.z * per_z;
   const int kz1 = (kz0 + per_z < ksteps) ? kz0 + per_z : ksteps;
-  const int per_w = (kz1 - kz0 + 3) >> 2;
+  const int per_w = (kz1 - kz0 + NW - 1) / NW;
   const int ks0 = kz0 + wave * per_w;
   int nks = kz1 - ks0;
   nks = nks < 0 ? 0 : (nks > per_w ? per_w : nks);
@@ -83,14 +88,16 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   // The four waves' partial sums of a quad are therefore four ds_read_b128 at consecutive-lane addresses (conflict-free; the
   // former one-column-per-thread walk read single floats 64 apart: 4-way bank conflicts, 60 % of the kernel's LDS cycles).
   constexpr int QUADS = NT * MT * 64;
-  constexpr int EPI_ITERS = (QUADS + 255) / 256;
+  constexpr int EPI_ITERS = (QUADS + NTHR - 1) / NTHR;
   // bias of this thread's columns and, for DEPI_SELF_QKV, the cache position of its rows: loaded up front so that the epilogue
   // has no dependent memory round trip of its own
   float4 bias_v[EPI_ITERS];
+  float4 lns_v[EPI_ITERS];     // ACT_BF16_LN: s of this thread's columns
+  float4 xold_v[EPI_ITERS];    // DEPI_RESOLVE: the residual tile this thread finishes
   int pos_v[EPI_ITERS];
 #pragma unroll
   for (int it = 0; it < EPI_ITERS; it++) {
-    const int qd = tid + 256 * it;
+    const int qd = tid + NTHR * it;
     const int ln = qd & 63, tj = (qd >> 6) % MT, ti = (qd >> 6) / MT;
     const int n_ = n0 + 16 * ti + 4 * (ln >> 4);
     bias_v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,6 +113,13 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     if (EPI == DEPI_SELF_QKV) {
       const int m_ = m0 + 16 * tj + (ln & 15);
       pos_v[it] = p.pos[m_ < p.M ? m_ : p.M - 1];
+    }
+    lns_v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACT == ACT_BF16_LN && qd < QUADS && n_ + 3 < p.N) lns_v[it] = *(const float4*)(p.ln_s + n_);
+    xold_v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == DEPI_RESOLVE && qd < QUADS) {
+      const int m_ = m0 + 16 * tj + (ln & 15);
+      xold_v[it] = *(const float4*)(p.xres + (long)(m_ < p.M ? m_ : p.M - 1) * p.N + (n_ + 3 < p.N ? n_ : 0));
     }
   }
 
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
     }
   }
   bf16x8 af[MT][KMAX];
-  if (ACT == ACT_BF16) {
+  if (BF16IN) {
 #pragma unroll
     for (int j = 0; j < MT; j++) {
       int m = m0 + 16 * j + l15;
@@ -140,6 +154,27 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
   }
 
   // ---------------- 2. activation staging ----------------
+  if (ACT == ACT_BF16_LN) {
+    // (mean, rstd) of the block's rows from the producer's per-tile statistics: four threads per row, each a quarter of the K / 16
+    // tiles in order, combined (q0 + q1) + (q2 + q3) -- a fixed order, whatever tile geometry this block has
+    if (tid < MROWS * 4) {
+      const int r = tid >> 2, qt = tid & 3;
+      int m = m0 + r;
+      m = m < p.M ? m : p.M - 1;
+      const int t4 = (K >> 4) >> 2;
+      const float2* sp = p.ln_stats + (long)m * (K >> 4) + qt * t4;
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = 0; i < t4; i++) {
+        const float2 v = sp[i];
+        s1 += v.x; s2 += v.y;
+      }
+      s1 += dpp_mov<CCX_DPP_QUAD_XOR1>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR1>(s2);
+      s1 += dpp_mov<CCX_DPP_QUAD_XOR2>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR2>(s2);
+      const float mean = s1 / (float)K;
+      const float var = fmaf(-mean, mean, s2 / (float)K);
+      if (qt == 0) lnst[r] = make_float2(mean, rsqrtf(fmaxf(var, 0.f) + p.eps));
+    }
+  }
   if (ACT == ACT_LN) {
     // x_eff = x + sum of pending split-K partials; LayerNorm(x_eff) -> bf16 LDS rows (K <= 1024).
     // A wave owns live rows wave, wave+4, ... and handles two of them per pass.
@@ -267,7 +302,7 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 #pragma unroll
   for (int k = 0; k < KMAX; k++) {
     if (k < nks) {
-      if (ACT != ACT_BF16) {
+      if (!BF16IN) {
 #pragma unroll
         for (int j = 0; j < MT; j++)
           af[j][k] = *(const bf16x8*)(act_s + (long)(16 * j + l15) * lds_ld + 8 * h4 + 32 * (ks0 + k));
@@ -290,15 +325,42 @@ __global__ __launch_bounds__(256) void dec_linear_kernel(DecLinearParams p) {
 
 #pragma unroll
   for (int it = 0; it < EPI_ITERS; it++) {
-    const int qd = tid + 256 * it;
+    const int qd = tid + NTHR * it;
     if (qd >= QUADS) break;
     const int ln = qd & 63, j = (qd >> 6) % MT, i = (qd >> 6) / MT;
     const int m = m0 + 16 * j + (ln & 15), n = n0 + 16 * i + 4 * (ln >> 4);
+    if (EPI == DEPI_RESOLVE) {
+      // whole waves stay together here (the statistics go through lane swaps); N is a multiple of the block's columns
+      f32x4 v = *(const f32x4*)(red + (((0 * NT + i) * MT + j) * 64 + ln) * 4);
+#pragma unroll
+      for (int w = 1; w < NW; w++) v += *(const f32x4*)(red + (((w * NT + i) * MT + j) * 64 + ln) * 4);
+      v[0] = (v[0] + bias_v[it].x) + xold_v[it].x; v[1] = (v[1] + bias_v[it].y) + xold_v[it].y;
+      v[2] = (v[2] + bias_v[it].z) + xold_v[it].z; v[3] = (v[3] + bias_v[it].w) + xold_v[it].w;
+      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+      float s2 = fmaf(v[3], v[3], fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
+      s1 += lane_xor16(s1); s2 += lane_xor16(s2);        // the four quads of a row's 16-column tile sit 16 lanes apart
+      s1 += lane_xor32(s1); s2 += lane_xor32(s2);
+      if (m < p.M && n < p.N) {
+        *(float4*)(p.xres + (long)m * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+        *(uint2*)(p.xb + (long)m * p.N + n) = pk;
+        if ((ln >> 4) == 0) p.st_out[(long)m * (p.N >> 4) + (n >> 4)] = make_float2(s1, s2);
+      }
+      continue;
+    }
     if (n >= p.N || m >= p.M) continue;
     f32x4 v = *(const f32x4*)(red + (((0 * NT + i) * MT + j) * 64 + ln) * 4);
 #pragma unroll
-    for (int w = 1; w < 4; w++) v += *(const f32x4*)(red + (((w * NT + i) * MT + j) * 64 + ln) * 4);      // same order as before: w = 0..3
-    v[0] += bias_v[it].x; v[1] += bias_v[it].y; v[2] += bias_v[it].z; v[3] += bias_v[it].w;
+    for (int w = 1; w < NW; w++) v += *(const f32x4*)(red + (((w * NT + i) * MT + j) * 64 + ln) * 4);      // same order as before: w = 0..3
+    if (ACT == ACT_BF16_LN) {
+      // LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + c, every multiply-add an explicit fmaf
+      const float2 ms = lnst[16 * j + (ln & 15)];
+      v[0] = fmaf(ms.y, fmaf(-ms.x, lns_v[it].x, v[0]), bias_v[it].x); v[1] = fmaf(ms.y, fmaf(-ms.x, lns_v[it].y, v[1]), bias_v[it].y);
+      v[2] = fmaf(ms.y, fmaf(-ms.x, lns_v[it].z, v[2]), bias_v[it].z); v[3] = fmaf(ms.y, fmaf(-ms.x, lns_v[it].w, v[3]), bias_v[it].w);
+    } else {
+      v[0] += bias_v[it].x; v[1] += bias_v[it].y; v[2] += bias_v[it].z; v[3] += bias_v[it].w;
+    }
     const bool full = n + 3 < p.N;       // N is a multiple of 4 everywhere but a guard costs nothing
     if (EPI == DEPI_BF16_GELU) {
       bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
@@ -383,6 +445,51 @@ __global__ __launch_bounds__(256) void dec_resolve_ln_kernel(const float* __rest
   }
 }
 
+// Stand-alone resolve for the LayerNorm-free chain: x += sum of the pending split-K slabs (in place: a wave owns its row and reads all of
+// it before it writes), a bf16 copy of the new row and (sum, sum of squares) per 16-column tile -- what DEPI_RESOLVE leaves behind,
+// for the one producer that keeps its split-K slabs (the K = 3072 second MLP linear).  One wave per row; the statistics of a tile
+// are the four lanes' quads in the order (q0 + q1) + (q2 + q3), as in the linear's epilogue.
+__global__ __launch_bounds__(256) void dec_resolve_stats_kernel(float* __restrict__ x, const float* __restrict__ pend, int pend_n,
+                                                                long pend_stride, bf16_t* __restrict__ xb, float2* __restrict__ st,
+                                                                int M, int K) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int nv = K >> 2;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = lane + 64 * i;
+    const int ic = idx < nv ? idx : 0;
+    float4 a = ((const float4*)(x + (long)m * K))[ic];
+    float4 q[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) q[s] = ((const float4*)(pend + (long)(s < pend_n ? s : 0) * pend_stride + (long)m * K))[ic];
+#pragma unroll
+    for (int s = 0; s < 4; s++) a = ln_add_pend(a, s < pend_n ? 1.f : 0.f, q[s]);
+    float s1 = (a.x + a.y) + (a.z + a.w);
+    float s2 = fmaf(a.w, a.w, fmaf(a.z, a.z, fmaf(a.y, a.y, a.x * a.x)));
+    // lanes 4 t .. 4 t + 3 hold the four quads of tile t of this pass
+    s1 += dpp_mov<CCX_DPP_QUAD_XOR1>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR1>(s2);
+    s1 += dpp_mov<CCX_DPP_QUAD_XOR2>(s1); s2 += dpp_mov<CCX_DPP_QUAD_XOR2>(s2);
+    if (idx < nv) {
+      ((float4*)(x + (long)m * K))[idx] = a;
+      uint2 pk;
+      pk.x = pack_bf16x2(a.x, a.y); pk.y = pack_bf16x2(a.z, a.w);
+      ((uint2*)(xb + (long)m * K))[idx] = pk;
+      if ((lane & 3) == 0) st[(long)m * (K >> 4) + (idx >> 2)] = make_float2(s1, s2);
+    }
+  }
+}
+
+int ccx_launch_dec_resolve_stats(ccx_ctx* ctx, float* x, const float* pend, int pend_n, long pend_stride, bf16_t* xb, float2* st, int M,
+                                 int K, hipStream_t stream) {
+  CCX_REQUIRE(ctx, K % 16 == 0 && K <= 1024 && pend_n >= 0 && pend_n <= 4, "dec_resolve_stats: K=%d / %d slabs unsupported", K, pend_n);
+  ccx_prof_scope ps(ctx, stream, "dec_resolve_stats_kernel", 0.0, (double)M * K * (4.0 * (2 + pend_n) + 2.0));
+  hipLaunchKernelGGL(dec_resolve_stats_kernel, dim3(ccx_cdiv(M, 4)), dim3(256), 0, stream, x, pend, pend_n, pend_stride, xb, st, M, K);
+  CCX_CHECK_LAUNCH(ctx);
+  return CCX_OK;
+}
+
 // Stand-alone split-KV combine -> bf16 attention output [M][H*64] (used instead of the in-GEMV prologue when
 // many sequences are decoded: every weight-panel block would otherwise redo the whole combine).
 __global__ __launch_bounds__(256) void dec_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
@@ -457,25 +564,27 @@ int ccx_launch_dec_resolve_ln(ccx_ctx* ctx, const float* x, const float* pend, i
   return CCX_OK;
 }
 
-template <int MT, int NT, int KMAX, int ACT, int EPI>
+template <int MT, int NT, int KMAX, int ACT, int EPI, int NW = 4>
 static int launch_dec_linear_inst(ccx_ctx* ctx, const DecLinearParams& p, int ksplit, hipStream_t stream) {
   const int MROWS = 16 * MT, BN = 16 * NT;
-  size_t act_bytes = (ACT == ACT_BF16) ? 0 : ccx_align((size_t)MROWS * (p.K + 8) * 2, 16);
-  size_t red_bytes = (size_t)4 * NT * MT * 64 * 4 * 4;
-  size_t lds = act_bytes + red_bytes;
+  size_t act_bytes = (ACT == ACT_BF16 || ACT == ACT_BF16_LN) ? 0 : ccx_align((size_t)MROWS * (p.K + 8) * 2, 16);
+  size_t red_bytes = (size_t)NW * NT * MT * 64 * 4 * 4;
+  size_t lds = act_bytes + red_bytes + (ACT == ACT_BF16_LN ? (size_t)MROWS * 8 : 0);
   CCX_REQUIRE(ctx, lds <= 160 * 1024, "dec_linear: LDS %zu too large", lds);
-  CCX_REQUIRE(ctx, ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), 4) <= KMAX, "dec_linear: K=%d / split %d exceeds the prefetch depth %d", p.K, ksplit, KMAX);
+  CCX_REQUIRE(ctx, ccx_cdiv(ccx_cdiv(p.K / 32, ksplit), NW) <= KMAX, "dec_linear: K=%d / split %d exceeds the prefetch depth %d", p.K, ksplit, KMAX);
+  if (ACT == ACT_BF16_LN) CCX_REQUIRE(ctx, p.ln_stats && p.ln_s && p.bias && ksplit == 1 && p.K % 64 == 0 && p.N % 4 == 0, "dec_linear: bad LayerNorm-algebra arguments");
+  if (EPI == DEPI_RESOLVE) CCX_REQUIRE(ctx, p.xres && p.xb && p.st_out && ksplit == 1 && p.N % BN == 0, "dec_linear: bad resolve arguments (N=%d, %d columns per block)", p.N, BN);
   static ccx_lds_optin optin;
-  if (lds > 64 * 1024) CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI>));
+  if (lds > 64 * 1024) CCX_HIP(ctx, optin.ensure(ctx->device, (const void*)dec_linear_kernel<MT, NT, KMAX, ACT, EPI, NW>));
   dim3 grid(ccx_cdiv(p.N, BN), ccx_cdiv(p.M, MROWS), ksplit);
   {
     // weight-streaming GEMV: algorithmic bytes = the weight matrix once (+ small activations)
     // labelled like rocprofv3 labels the instantiation, so that both rank the same kernels
     static const std::string label = "dec_linear_kernel<" + std::to_string(MT) + ", " + std::to_string(NT) + ", " + std::to_string(KMAX) +
-                                     ", " + std::to_string(ACT) + ", " + std::to_string(EPI) + ">";
+                                     ", " + std::to_string(ACT) + ", " + std::to_string(EPI) + (NW == 4 ? "" : ", " + std::to_string(NW)) + ">";
     ccx_prof_scope ps(ctx, stream, label.c_str(), 2.0 * p.M * (double)p.N * p.K,
                       2.0 * (double)p.N * p.K + 2.0 * p.M * ((double)p.K + p.N));
-    hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((dec_linear_kernel<MT, NT, KMAX, ACT, EPI, NW>), grid, dim3(64 * NW), lds, stream, p);
   }
   CCX_CHECK_LAUNCH(ctx);
   return CCX_OK;
@@ -499,6 +608,7 @@ static int launch_dec_linear_mt(ccx_ctx* ctx, const DecLinearParams& p, int kspl
 
 int ccx_dec_linear_ksplit(int K, int epi) {
   // prefetch depth is 8 k-steps (256 elements) per wave, 4 waves per block
+  if (epi == DEPI_RESOLVE) return 1;   // the residual is added in place: one block owns all of K (12 waves beyond K = 1024)
   int ks = ccx_cdiv(K, 1024);
   if (epi != DEPI_PARTIAL) return ks;  // only partial outputs can be split across blocks
   return ks < 1 ? 1 : ks;
@@ -511,6 +621,31 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
   const int ksplit = ccx_dec_linear_ksplit(p.K, epi);
   CCX_REQUIRE(ctx, epi == DEPI_PARTIAL || ksplit == 1, "dec_linear: K=%d needs a split-K (partial) epilogue", p.K);
   CCX_REQUIRE(ctx, epi != DEPI_PARTIAL || p.pend_stride >= (long)p.M * p.ldo, "dec_linear: pend_stride too small");
+  // ---- the LayerNorm-free chain (X-stream path): consumers with the LayerNorm algebra in the epilogue, producers that resolve
+  // the residual themselves.  ONE tile geometry rule for every row count (MT by rows, 32-column blocks from 128 rows on): per
+  // output the arithmetic is the same in all of them, and the statistics are kept per 16-column tile, so a row's numbers do not
+  // depend on its lane
+  if (act == ACT_BF16_LN || epi == DEPI_RESOLVE) {
+    CCX_REQUIRE(ctx, (act == ACT_BF16_LN) != (epi == DEPI_RESOLVE) && (act == ACT_BF16_LN || act == ACT_BF16), "dec_linear: LayerNorm-free modes do not combine");
+    const bool wide_rows_ = p.M >= 128;
+    if (epi == DEPI_RESOLVE && p.K > 1024) {
+      // K = 3072 without split-K slabs: 12 waves x 8 k-steps, 32 rows x 32 columns per block (170 registers per thread at three waves per SIMD)
+      CCX_REQUIRE(ctx, p.K <= 12 * 8 * 32, "dec_linear: K=%d too deep for the 12-wave resolve kernel", p.K);
+      if (p.M <= 16) return launch_dec_linear_inst<1, 2, 8, ACT_BF16, DEPI_RESOLVE, 12>(ctx, p, 1, stream);
+      return launch_dec_linear_inst<2, 2, 8, ACT_BF16, DEPI_RESOLVE, 12>(ctx, p, 1, stream);
+    }
+#define CCX_LNFREE(ACT_, EPI_)                                                                                           \
+    do {                                                                                                                   \
+      if (wide_rows_) return launch_dec_linear_mt<2, ACT_, EPI_>(ctx, p, 1, stream);                                       \
+      return launch_dec_linear_mt<1, ACT_, EPI_>(ctx, p, 1, stream);                                                       \
+    } while (0)
+    if (epi == DEPI_RESOLVE) CCX_LNFREE(ACT_BF16, DEPI_RESOLVE);
+    if (epi == DEPI_SELF_QKV) CCX_LNFREE(ACT_BF16_LN, DEPI_SELF_QKV);
+    if (epi == DEPI_BF16_GELU) CCX_LNFREE(ACT_BF16_LN, DEPI_BF16_GELU);
+    if (epi == DEPI_F32) CCX_LNFREE(ACT_BF16_LN, DEPI_F32);
+#undef CCX_LNFREE
+    return ccx_fail(ctx, CCX_ERR_ARG, "dec_linear: unsupported LayerNorm-free act=%d epi=%d", act, epi);
+  }
   // wide-N layers (logits) use 64-row weight panels per block, narrow ones 16 to spread over more CUs
   const bool wide = p.N >= 8192;
   if (act == ACT_BF16 && epi == DEPI_F32 && wide) return launch_dec_linear_mt<4, ACT_BF16, DEPI_F32>(ctx, p, 1, stream);

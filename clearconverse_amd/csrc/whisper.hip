@@ -62,6 +62,10 @@ struct DecLayer {
   bf16_t* W1_plain = nullptr;   // fc1 once more in plain row-major [F][D] for the tiled GEMM (lanes of >= 256 rows, prefill)
   bf16_t* WckT = nullptr;       // cross_attn.key.weight re-laid per head [H][D][64] for the expanded query (cross_x.hip)
   bf16_t* Wcq_plain = nullptr;  // cross_attn.query.weight in plain row-major [D][D] (dec_xq_fused_kernel)
+  // LayerNorm-free chain (decoder.h, ACT_BF16_LN): gamma folded into the consumer weights, s_n = sum_k (gamma o W)_nk over the bf16
+  // values the MFMAs see, c_n = sum_k beta_k W_nk + b_n.  Wqkv_g / W1_g fragment-packed, Wcq_g plain row-major
+  bf16_t *Wqkv_g = nullptr, *Wcq_g = nullptr, *W1_g = nullptr;
+  float *sqkv = nullptr, *cqkv = nullptr, *scq = nullptr, *ccq = nullptr, *s1 = nullptr, *c1 = nullptr;
   float *bqkv, *bo, *bcq, *bckv, *bco, *b1, *b2;
   bf16_t *crossK, *crossV, *selfK, *selfV;
 };
@@ -147,6 +151,12 @@ struct ccx_whisper {
   int last_cross_path = -1;                  // ccx_whisper_last_cross_path: 0 kv16, 1 kv_stream, 2 xa_stream
   int kv_cap = 0, kv_ready = 0;
   bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
+  // LayerNorm-free chain: bf16 copy of the resolved residual rows and their (sum, sum of squares) per 16-column tile
+  bf16_t *dxb = nullptr, *pf_xb = nullptr;
+  float2 *dst2 = nullptr, *pf_st2 = nullptr;
+  bool lnfree = false;                       // CCX_DEC_LNFREE, read per decode
+  bool lnfree_built = false;                 // the folded weights exist (CCX_DEC_LNFREE was set when the instance was finalized)
+  int lnfree_mode = 0;                       // 1: every producer resolves in place (12-wave second MLP linear); 2: that one keeps split-K slabs
   float *xs_po = nullptr, *xs_pml = nullptr, *pf_xs_po = nullptr, *pf_xs_pml = nullptr;   // key-half partials (cross_x.h)
   static constexpr int kLanePool = 8;
   hipStream_t lane_pool[kLanePool] = {};     // candidates; HIP streams share a few hardware queues and two streams on one
@@ -556,6 +566,36 @@ int ccx_whisper_finalize(ccx_whisper* w) {
           for (int dd = 0; dd < 64; dd++) wkt[((size_t)hh * D + f) * 64 + dd] = ckw->data[(size_t)(hh * 64 + dd) * D + f];
       TRY(up_bf16(w, &L.WckT, wkt.data(), wkt.size()));
       TRY(up_bf16(w, &L.Wcq_plain, cqw->data.data(), cqw->data.size()));
+      // LayerNorm folded into the three consumers of a normalised row (q|k|v, the cross-attention query, the first MLP linear):
+      // only built when the experiment is asked for at creation time (CCX_DEC_LNFREE set; 113 MB per small.en instance)
+      w->lnfree_built = getenv("CCX_DEC_LNFREE") != nullptr;
+      if (w->lnfree_built) {
+      auto fold = [&](const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& g, const std::vector<float>& bt,
+                      int N, std::vector<float>& Wg, std::vector<float>& sv, std::vector<float>& cv) {
+        Wg.resize((size_t)N * D); sv.resize(N); cv.resize(N);
+        for (int n = 0; n < N; n++) {
+          double ss = 0.0, cc = 0.0;
+          for (int k = 0; k < D; k++) {
+            const float v = g[k] * W[(size_t)n * D + k];
+            Wg[(size_t)n * D + k] = v;
+            const uint32_t bits = (uint32_t)host_f32_to_bf16(v) << 16;
+            float r;
+            memcpy(&r, &bits, 4);
+            ss += (double)r;                                   // what the MFMA sums: the bf16-rounded products
+            cc += (double)bt[k] * (double)W[(size_t)n * D + k];
+          }
+          sv[n] = (float)ss;
+          cv[n] = (float)(cc + (double)bias[n]);
+        }
+      };
+      std::vector<float> Wg, sv, cv;
+      fold(wqkv, bqkv, l1g->data, l1b->data, 3 * D, Wg, sv, cv);
+      TRY(up_bf16_packed(w, &L.Wqkv_g, Wg.data(), 3 * D, D, 16)); TRY(up_f32(w, &L.sqkv, sv.data(), sv.size())); TRY(up_f32(w, &L.cqkv, cv.data(), cv.size()));
+      fold(cqw->data, cqb->data, lcg->data, lcb->data, D, Wg, sv, cv);
+      TRY(up_bf16(w, &L.Wcq_g, Wg.data(), Wg.size())); TRY(up_f32(w, &L.scq, sv.data(), sv.size())); TRY(up_f32(w, &L.ccq, cv.data(), cv.size()));
+      fold(m0w->data, m0b->data, l2g->data, l2b->data, F, Wg, sv, cv);
+      TRY(up_bf16_packed(w, &L.W1_g, Wg.data(), F, D, 16)); TRY(up_f32(w, &L.s1, sv.data(), sv.size())); TRY(up_f32(w, &L.c1, cv.data(), cv.size()));
+      }
     }
     const size_t ck = (size_t)w->kv_cap * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
     TRY(dev_alloc(w, &L.crossK, ck, true)); TRY(dev_alloc(w, &L.crossV, ck, true));
@@ -596,6 +636,10 @@ int ccx_whisper_finalize(ccx_whisper* w) {
     TRY(dev_alloc(w, &w->xs_pml, ccx_xs_part_ml_elems(B), true));
     TRY(dev_alloc(w, &w->pf_xs_po, ccx_xs_part_o_elems((size_t)B * ccx_whisper::kPrefillMax, H, D), true));
     TRY(dev_alloc(w, &w->pf_xs_pml, ccx_xs_part_ml_elems((size_t)B * ccx_whisper::kPrefillMax), true));
+    TRY(dev_alloc(w, &w->dxb, (size_t)B * D, true));
+    TRY(dev_alloc(w, &w->pf_xb, (size_t)B * ccx_whisper::kPrefillMax * D, true));
+    TRY(dev_alloc(w, &w->dst2, (size_t)B * (D / 16), true));
+    TRY(dev_alloc(w, &w->pf_st2, (size_t)B * ccx_whisper::kPrefillMax * (D / 16), true));
   }
   TRY(dev_alloc(w, &w->dx, (size_t)B * D, true));
   TRY(dev_alloc(w, &w->dx2, (size_t)B * D, true));
@@ -1021,6 +1065,81 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   };
   // diagnostic only (results are garbage): CCX_ABLATE=cross drops the cross attention launches, =chain everything else of a layer
   static const int ablate = [] { const char* e = getenv("CCX_ABLATE"); return !e ? 0 : (!strcmp(e, "cross") ? 1 : (!strcmp(e, "chain") ? 2 : 0)); }();
+  // ---- the LayerNorm-free chain of the X-stream path (CCX_DEC_LNFREE=1): 9 launches per layer and no stand-alone resolve / LayerNorm.
+  // The PRODUCERS of the residual stream (self-attention out, cross-attention out, second MLP linear: DEPI_RESOLVE) add their product
+  // to the stream in place -- no split-K slabs, K = 3072 goes to 12 waves per block -- and leave a bf16 copy of the new rows plus
+  // (sum, sum of squares) per 16-column tile; the CONSUMERS of a normalised row (q|k|v, the cross-attention query inside the
+  // expansion, the first MLP linear: ACT_BF16_LN) read the bf16 rows as they are and apply the LayerNorm algebraically in their
+  // epilogue (gamma folded into the weights at load time).  One set of kernels for every row count, statistics per tile in a fixed
+  // order: a row's numbers do not depend on its lane.  Layer 0 normalises the step's embedding the old way (nothing produced it).
+  if (w->lnfree && w->xs_active && ablate == 0) {
+    bf16_t* xb = pre ? w->pf_xb : w->dxb + ro * D;
+    float2* st2 = pre ? w->pf_st2 : w->dst2 + ro * (D / 16);
+    auto consumer = [&](int epi, const bf16_t* Wg, const float* sv, const float* cv, int N, void* out, long ldo, DecLinearParams* extra) -> int {
+      DecLinearParams lp;
+      if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
+      lp.M = B; lp.N = N; lp.K = D; lp.W = Wg; lp.ldw = D; lp.bias = cv; lp.ln_s = sv; lp.ln_stats = st2; lp.eps = 1e-5f;
+      lp.act = xb; lp.lda = D; lp.out = out; lp.ldo = ldo;
+      return ccx_launch_dec_linear(ctx, ACT_BF16_LN, epi, lp, stream);
+    };
+    auto producer = [&](const bf16_t* W, const float* bias, int K, const bf16_t* a) -> int {
+      DecLinearParams lp;
+      memset(&lp, 0, sizeof(lp));
+      lp.M = B; lp.N = D; lp.K = K; lp.W = W; lp.ldw = K; lp.bias = bias; lp.act = a; lp.lda = K;
+      lp.xres = cur; lp.xb = xb; lp.st_out = st2;
+      return ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_RESOLVE, lp, stream);
+    };
+    for (int l = 0; l < d.n_text_layer; l++) {
+      const DecLayer& L = w->dec[l];
+      DecLinearParams ex;
+      memset(&ex, 0, sizeof(ex));
+      ex.cache_k = L.selfK + self_off; ex.cache_v = L.selfV + self_off; ex.cache_T = Tc; ex.pos = pos; ex.row_seq = row_seq;
+      if (l == 0) TRY(ln_linear(DEPI_SELF_QKV, L.Wqkv, L.bqkv, 3 * D, L.ln1_g, L.ln1_b, dq, D, &ex));
+      else {
+        // (CCX_DEC_LNFREE=2: the second MLP linear kept its split-K slabs -- fold them in here, one small launch)
+        if (pend_n > 0) { TRY(ccx_launch_dec_resolve_stats(ctx, cur, pend, pend_n, pstride, xb, st2, B, D, stream)); pend_n = 0; }
+        TRY(consumer(DEPI_SELF_QKV, L.Wqkv_g, L.sqkv, L.cqkv, 3 * D, dq, D, &ex));
+      }
+      stamp(16, 2);
+      DecAttnParams ap;
+      memset(&ap, 0, sizeof(ap));
+      ap.q = dq; ap.k = L.selfK + self_off; ap.v = L.selfV + self_off; ap.H = H; ap.kv_T = Tc; ap.pos = pos; ap.scale_log2e = scale_log2e;
+      ap.out_bf16 = dattn; ap.row_seq = row_seq;
+      TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
+      stamp(17, 2);
+      TRY(producer(L.Wo, L.bo, D, dattn));
+      stamp(18, 2);
+      stamp(1, 1);
+      if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
+      {
+        XsParams xp;
+        memset(&xp, 0, sizeof(xp));
+        xp.xb = xb; xp.ln_stats = st2; xp.ln_s = L.scq; xp.Wq = L.Wcq_g; xp.bq = L.ccq; xp.eps = 1e-5f;
+        xp.WkT = L.WckT; xp.xq = pre ? w->pf_xq : w->xq + ro * H * D;
+        xp.part_o = pre ? w->pf_xs_po : w->xs_po + ccx_xs_part_o_elems(ro, H, D);
+        xp.part_ml = pre ? w->pf_xs_pml : w->xs_pml + ccx_xs_part_ml_elems(ro);
+        xp.X = pre ? w->xa : w->xa + ro * (long)d.n_audio_ctx * D; xp.x_seq_stride = (long)d.n_audio_ctx * D; xp.row_seq = row_seq;
+        xp.Wv = L.Wckv + (long)D * D; xp.bv = L.bckv + D; xp.out = dattn;
+        xp.rows = B; xp.H = H; xp.S = d.n_audio_ctx; xp.D = D; xp.scale_log2e = scale_log2e;
+        xp.lds_pad = (w->cross_lds_pad > 0 && !pre) ? 65536 : 0;
+        xp.rows_per_seq = pre ? prefill_rows : 0;
+        TRY(ccx_launch_xs_cross_attention(ctx, xp, stream));
+      }
+      stamp(2, 1);
+      TRY(producer(L.Wco, L.bco, D, dattn));
+      stamp(19, 2);
+      TRY(consumer(DEPI_BF16_GELU, L.W1_g, L.s1, L.c1, F, dffn, F, nullptr));
+      stamp(20, 2);
+      if (w->lnfree_mode == 2 && F > 1024) TRY(partial_linear(ACT_BF16, L.W2, L.b2, F, dffn));      // split-K slabs, resolved by the next consumer
+      else TRY(producer(L.W2, L.b2, F, dffn));
+      stamp(21, 2);
+    }
+    TRY(ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, w->lnd_g, w->lnd_b, dxn, nullptr, B, D, 1e-5f, stream));
+    if (pre) return CCX_OK;
+    TRY(dec_head(w, b0, B, logits, ld, select, sample_len, max_prompt, n_done, stream));
+    stamp(3, 1);
+    return CCX_OK;
+  }
   for (int l = 0; l < d.n_text_layer; l++) {
     const DecLayer& L = w->dec[l];
     if (ablate == 2 && w->xs_active) {
@@ -1344,6 +1463,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     w->cross_stream = lean;
     { const char* e = getenv("CCX_FUSE_CROSS_Q"); w->fuse_cross_q = e ? (atoi(e) != 0) : 1; }      // read per decode: tests flip it
     { const char* e = getenv("CCX_DEC_LN_FUSE_NT"); w->ln_fuse_nt = e ? atoi(e) : 0; }
+    { const char* e = getenv("CCX_DEC_LNFREE"); w->lnfree_mode = (e && w->lnfree_built) ? atoi(e) : 0; w->lnfree = w->lnfree_mode != 0; }
     // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight.  The claim only exists to
     // leave room for the OTHER lanes' chain kernels: a single lane runs uncapped.
     w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? (lean ? 98304 : 65536) : 0);
@@ -1393,7 +1513,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8) | ((w->xs_fuse_q ? 1 : 0) << 9) | (w->ln_fuse_nt << 10), i};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8) | ((w->xs_fuse_q ? 1 : 0) << 9) | (w->ln_fuse_nt << 10) | (w->lnfree_mode << 16), i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

@@ -132,3 +132,4 @@ def test_argument_errors(ccx_ctx):
     q3, wk3, wv3, bv3, xa3, _ = _case(1, 3, 64, 1, 1)
     with pytest.raises(_lib.CcxError):
         _run(ccx_ctx, q3, wk3, wv3, bv3, xa3, None, 3)            # width 192 is not instantiated
+

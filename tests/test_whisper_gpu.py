@@ -589,3 +589,41 @@ def test_long_prompts_are_prefilled_in_passes_of_16_positions(ccx_ctx, monkeypat
                 _oracle_accepts(orc, xa[i:i + 1], prompts[i], a[i], 8, 0.08)
     finally:
         m.close()
+
+
+def test_layernorm_free_chain_experiment_matches_the_default_chain(ccx_ctx, monkeypatch):
+    """CCX_DEC_LNFREE (experimental, off by default: measured 2 - 5 % slower, profiles/r04_ab_decode_lnfree_chain.txt): the decode chain of
+    the X-stream path without stand-alone resolve / LayerNorm launches -- producers add their product to the residual stream in
+    place and leave bf16 rows + per-tile statistics, consumers apply the LayerNorm algebraically in their epilogue (csrc/decoder.hip
+    DEPI_RESOLVE / ACT_BF16_LN, cross_x.hip dec_xq_lnfree_kernel).  Same tokens as the default chain, log-probabilities to rounding,
+    every token accepted by the oracle, and a sequence's numbers independent of its batch (4 alone = 40 in lanes, bit for bit)."""
+    from clearconverse_amd.whisper import WhisperModel
+    monkeypatch.setenv("CCX_DEC_LNFREE", "0")              # the folded weights are built when the instance is created
+    dims = WhisperDims.mini(n_layer=2, n_state=128)
+    sd = synthetic_whisper_state_dict(dims, seed=3)
+    m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
+    try:
+        rules, _ = _rules()
+        clips, n, dev = _clips([6.0, 11.0, 3.0, 8.0])
+        g = np.random.default_rng(9)
+        prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot_prev] + [int(x) for x in g.integers(1000, 40000, 20)] + [rules.sot], [rules.sot_prev, 77, rules.sot]]
+        monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")
+        m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
+        base = m.decode_greedy(prompts, sample_len=40)
+        orc = _oracle(dims, sd)
+        for mode in ("1", "2"):
+            monkeypatch.setenv("CCX_DEC_LNFREE", mode)
+            m.log_mel(dev, n); m.encode(4)
+            small = m.decode_greedy(prompts, sample_len=40)
+            big = dev.repeat(10, 1).contiguous()
+            m.log_mel(big, n * 10); m.encode(40)
+            large = m.decode_greedy(prompts * 10, sample_len=40)
+            for i in range(40):
+                assert large[i]["tokens"] == small[i % 4]["tokens"] and large[i]["sum_logprob"] == small[i % 4]["sum_logprob"], (mode, i)
+            for i in range(4):
+                _oracle_accepts(orc, xa[i:i + 1], prompts[i], small[i], 40, 0.05)
+                if small[i]["tokens"] == base[i]["tokens"]:
+                    within("whisper mini: |sum_logprob LayerNorm-free chain - default chain| / max(1, |.|)",
+                           abs(small[i]["sum_logprob"] - base[i]["sum_logprob"]) / max(1.0, abs(base[i]["sum_logprob"])), 2e-3, (mode, i))
+    finally:
+        m.close()

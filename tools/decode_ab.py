@@ -11,6 +11,7 @@ from clearconverse_amd.whisper import WhisperModel
 B, steps = int(sys.argv[1]), int(sys.argv[2])
 configs = sys.argv[3:] or ["-"]
 dims = WhisperDims.small_en()
+os.environ.setdefault("CCX_DEC_LNFREE", "0")      # build the folded weights of the LayerNorm-free chain (off until a configuration asks for it)
 m = WhisperModel(dims, synthetic_whisper_state_dict(dims, seed=0), max_batch=B)
 rules = DecodeRules()
 clips = [synthetic_clip(i, 30.0) for i in range(8)]
