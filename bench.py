@@ -593,6 +593,20 @@ def main():
                                                           gemm_ms=round(enc_ms / prof_steps, 2), attention_ms=round(att_ms / prof_steps, 2),
                                                           layernorm_ms=round(ln_ms / prof_steps, 2), windows_per_step=wins // prof_steps,
                                                           gflop_per_window=round(gfl_win / 1e9, 1))
+        if roof_mfma is not None:
+            # what the matrix cores of this part sustain at the phased GEMM's footprint (tools/microbench_mfma_ceiling.hip, committed once
+            # per round): nothing but MFMAs on random operands, and the same with the main loop's LDS operand reads beside them
+            cf = sorted((ROOT / "profiles").glob("r*_mfma_ceiling.json"))
+            if cf:
+                cj = json.loads(cf[-1].read_text())
+                ceil = cj["mfma_with_lds_operand_reads"]["tflops"]
+                roof_mfma["measured_ceiling"] = dict(file=f"profiles/{cf[-1].name}", bare_mfma_tflops=cj["bare_mfma"]["tflops"],
+                                                     with_lds_operand_reads_tflops=ceil, shader_clock_mhz=cj["mfma_with_lds_operand_reads"]["shader_clock_mhz"],
+                                                     what="v_mfma_f32_16x16x32_bf16 only, 8 waves per CU, 128 accumulator registers, random bf16 operands")
+                roof_mfma["frac_of_measured_ceiling"] = round(roof_mfma["achieved"] / ceil, 4)
+                for k in ("whisper_encoder_gemms", "whisper_encoder_total"):
+                    if k in roof_mfma:
+                        roof_mfma[k]["frac_of_measured_ceiling"] = round(roof_mfma[k]["achieved"] / ceil, 4)
         stage_ms = {k: round(v[3] / prof_steps, 3) for k, v in agg.items()}
         stage_ms.update({k: round(v[0], 3) for k, v in per_step.items()})
 

@@ -569,7 +569,7 @@ int ccx_whisper_finalize(ccx_whisper* w) {
       // LayerNorm folded into the three consumers of a normalised row (q|k|v, the cross-attention query, the first MLP linear):
       // only built when the experiment is asked for at creation time (CCX_DEC_LNFREE set; 113 MB per small.en instance)
       w->lnfree_built = getenv("CCX_DEC_LNFREE") != nullptr;
-      if (w->lnfree_built) {
+      {
       auto fold = [&](const std::vector<float>& W, const std::vector<float>& bias, const std::vector<float>& g, const std::vector<float>& bt,
                       int N, std::vector<float>& Wg, std::vector<float>& sv, std::vector<float>& cv) {
         Wg.resize((size_t)N * D); sv.resize(N); cv.resize(N);
@@ -589,12 +589,15 @@ int ccx_whisper_finalize(ccx_whisper* w) {
         }
       };
       std::vector<float> Wg, sv, cv;
-      fold(wqkv, bqkv, l1g->data, l1b->data, 3 * D, Wg, sv, cv);
-      TRY(up_bf16_packed(w, &L.Wqkv_g, Wg.data(), 3 * D, D, 16)); TRY(up_f32(w, &L.sqkv, sv.data(), sv.size())); TRY(up_f32(w, &L.cqkv, cv.data(), cv.size()));
+      // the cross-attention query's fold is part of the DEFAULT chain (mode 3); the other two only exist for the experiments
       fold(cqw->data, cqb->data, lcg->data, lcb->data, D, Wg, sv, cv);
       TRY(up_bf16(w, &L.Wcq_g, Wg.data(), Wg.size())); TRY(up_f32(w, &L.scq, sv.data(), sv.size())); TRY(up_f32(w, &L.ccq, cv.data(), cv.size()));
-      fold(m0w->data, m0b->data, l2g->data, l2b->data, F, Wg, sv, cv);
-      TRY(up_bf16_packed(w, &L.W1_g, Wg.data(), F, D, 16)); TRY(up_f32(w, &L.s1, sv.data(), sv.size())); TRY(up_f32(w, &L.c1, cv.data(), cv.size()));
+      if (w->lnfree_built) {
+        fold(wqkv, bqkv, l1g->data, l1b->data, 3 * D, Wg, sv, cv);
+        TRY(up_bf16_packed(w, &L.Wqkv_g, Wg.data(), 3 * D, D, 16)); TRY(up_f32(w, &L.sqkv, sv.data(), sv.size())); TRY(up_f32(w, &L.cqkv, cv.data(), cv.size()));
+        fold(m0w->data, m0b->data, l2g->data, l2b->data, F, Wg, sv, cv);
+        TRY(up_bf16_packed(w, &L.W1_g, Wg.data(), F, D, 16)); TRY(up_f32(w, &L.s1, sv.data(), sv.size())); TRY(up_f32(w, &L.c1, cv.data(), cv.size()));
+      }
       }
     }
     const size_t ck = (size_t)w->kv_cap * H * w->Spad * 64, sk = (size_t)B * H * Tc * 64;
@@ -1072,7 +1075,13 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
   // expansion, the first MLP linear: ACT_BF16_LN) read the bf16 rows as they are and apply the LayerNorm algebraically in their
   // epilogue (gamma folded into the weights at load time).  One set of kernels for every row count, statistics per tile in a fixed
   // order: a row's numbers do not depend on its lane.  Layer 0 normalises the step's embedding the old way (nothing produced it).
-  if (w->lnfree && w->xs_active && ablate == 0) {
+  // (CCX_DEC_LNFREE=3: only the self-attention output projection resolves in place and only the cross-attention query uses the algebra --
+  //  the default chain without the twelve-fold resolve + LayerNorm inside dec_xq_fused_kernel; handled in the default loop below)
+  //  CCX_DEC_LNFREE=4: only the cross-attention output projection resolves in place and only the first MLP linear uses the algebra; 5: both)
+  const bool lnf_on = w->xs_active && ablate == 0;
+  const bool lnfree3 = lnf_on && (w->lnfree_mode == 3 || w->lnfree_mode == 5);
+  const bool lnfree4 = lnf_on && (w->lnfree_mode == 4 || w->lnfree_mode == 5);
+  if (w->lnfree && w->lnfree_mode < 3 && w->xs_active && ablate == 0) {
     bf16_t* xb = pre ? w->pf_xb : w->dxb + ro * D;
     float2* st2 = pre ? w->pf_st2 : w->dst2 + ro * (D / 16);
     auto consumer = [&](int epi, const bf16_t* Wg, const float* sv, const float* cv, int N, void* out, long ldo, DecLinearParams* extra) -> int {
@@ -1177,7 +1186,15 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     ap.out_bf16 = dattn; ap.row_seq = row_seq;
     TRY(ccx_launch_dec_attention(ctx, ap, B, 1, true, stream));
     stamp(17, 2);
-    TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
+    if (lnfree3) {
+      DecLinearParams lp;
+      memset(&lp, 0, sizeof(lp));
+      lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wo; lp.ldw = D; lp.bias = L.bo; lp.act = dattn; lp.lda = D;
+      lp.xres = cur; lp.xb = pre ? w->pf_xb : w->dxb + ro * D; lp.st_out = pre ? w->pf_st2 : w->dst2 + ro * (D / 16);
+      TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_RESOLVE, lp, stream));
+    } else {
+      TRY(partial_linear(ACT_BF16, L.Wo, L.bo, D, dattn));
+    }
     stamp(18, 2);
     // cross attention.  Small batches (<= 16 rows, d_model 768: the reference's one-window-per-call pattern): the query projection
     // LN(x) Wcq^T runs INSIDE the cross-attention blocks (ccx_launch_dec_cross_fused_q: one launch fewer per layer on a chain that
@@ -1186,7 +1203,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     // X-stream path: the query projection (with its resolve + LayerNorm) runs inside the expansion kernel -- one launch for three
     // (CCX_XS_FUSE_Q=0: the three launches)
     const bool xs_fused = w->xs_active && w->xs_fuse_q;
-    if (!fuse_q && !xs_fused) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
+    if (!fuse_q && !xs_fused && !lnfree3) TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));
     stamp(1, 1);
     if (l == 0 && stagger) CCX_HIP(ctx, hipEventRecord(stagger, stream));
     if (w->xs_active) {
@@ -1194,7 +1211,10 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       if (ablate != 1) {
         XsParams xp;
         memset(&xp, 0, sizeof(xp));
-        if (xs_fused) {
+        if (lnfree3) {
+          xp.xb = pre ? w->pf_xb : w->dxb + ro * D; xp.ln_stats = pre ? w->pf_st2 : w->dst2 + ro * (D / 16);
+          xp.ln_s = L.scq; xp.Wq = L.Wcq_g; xp.bq = L.ccq; xp.eps = 1e-5f;
+        } else if (xs_fused) {
           xp.x = cur; xp.pend = pend; xp.pend_n = pend_n; xp.pend_stride = pstride; xp.x_out = pend_n > 0 ? other : nullptr;
           xp.ln_g = L.lnc_g; xp.ln_b = L.lnc_b; xp.eps = 1e-5f; xp.Wq = L.Wcq_plain; xp.bq = L.bcq;
         }
@@ -1212,7 +1232,15 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
         TRY(ln_linear(DEPI_F32, L.Wcq, L.bcq, D, L.lnc_g, L.lnc_b, dq, D, nullptr));     // chain-only ablation: keep the resolve
       }
       stamp(2, 1);
-      TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+      if (lnfree4) {
+        DecLinearParams lp;
+        memset(&lp, 0, sizeof(lp));
+        lp.M = B; lp.N = D; lp.K = D; lp.W = L.Wco; lp.ldw = D; lp.bias = L.bco; lp.act = dattn; lp.lda = D;
+        lp.xres = cur; lp.xb = pre ? w->pf_xb : w->dxb + ro * D; lp.st_out = pre ? w->pf_st2 : w->dst2 + ro * (D / 16);
+        TRY(ccx_launch_dec_linear(ctx, ACT_BF16, DEPI_RESOLVE, lp, stream));
+      } else {
+        TRY(partial_linear(ACT_BF16, L.Wco, L.bco, D, dattn));
+      }
       stamp(19, 2);
     } else {
     memset(&ap, 0, sizeof(ap));
@@ -1263,6 +1291,12 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
       memset(&gp, 0, sizeof(gp));
       gp.A = dxn; gp.lda = D; gp.W = L.W1_plain; gp.ldw = D; gp.M = B; gp.N = F; gp.K = D; gp.bias = L.b1; gp.out = dffn; gp.ldo = F;
       TRY(ccx_launch_gemm(ctx, EPI_BF16_GELU, gp, stream));
+    } else if (lnfree4) {
+      DecLinearParams lp;
+      memset(&lp, 0, sizeof(lp));
+      lp.M = B; lp.N = F; lp.K = D; lp.W = L.W1_g; lp.ldw = D; lp.bias = L.c1; lp.ln_s = L.s1; lp.eps = 1e-5f;
+      lp.ln_stats = pre ? w->pf_st2 : w->dst2 + ro * (D / 16); lp.act = pre ? w->pf_xb : w->dxb + ro * D; lp.lda = D; lp.out = dffn; lp.ldo = F;
+      TRY(ccx_launch_dec_linear(ctx, ACT_BF16_LN, DEPI_BF16_GELU, lp, stream));
     } else {
       TRY(ln_linear(DEPI_BF16_GELU, L.W1, L.b1, F, L.ln2_g, L.ln2_b, dffn, F, nullptr));
     }
@@ -1463,7 +1497,12 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     w->cross_stream = lean;
     { const char* e = getenv("CCX_FUSE_CROSS_Q"); w->fuse_cross_q = e ? (atoi(e) != 0) : 1; }      // read per decode: tests flip it
     { const char* e = getenv("CCX_DEC_LN_FUSE_NT"); w->ln_fuse_nt = e ? atoi(e) : 0; }
-    { const char* e = getenv("CCX_DEC_LNFREE"); w->lnfree_mode = (e && w->lnfree_built) ? atoi(e) : 0; w->lnfree = w->lnfree_mode != 0; }
+    // default 3: the self-attention output projection resolves the residual in place and the cross-attention query applies its
+    // LayerNorm algebraically (no twelve-fold resolve + LayerNorm inside the expansion kernel; -1.0 ... -1.2 % per decode step);
+    // 0: round 3's chain; 1 / 2 / 4 / 5: the experiments of DESIGN.md section 2 (need the instance created with CCX_DEC_LNFREE set)
+    { const char* e = getenv("CCX_DEC_LNFREE"); w->lnfree_mode = e ? atoi(e) : 3;
+      if (w->lnfree_mode != 0 && w->lnfree_mode != 3 && !w->lnfree_built) w->lnfree_mode = 3;
+      w->lnfree = w->lnfree_mode != 0; }
     // lean streaming: ONE 4-wave block per CU (98 KB of claimed LDS), each wave with 8-16 KB in flight.  The claim only exists to
     // leave room for the OTHER lanes' chain kernels: a single lane runs uncapped.
     w->cross_lds_pad = forced_pad >= 0 ? forced_pad : (nl > 1 ? (lean ? 98304 : 65536) : 0);

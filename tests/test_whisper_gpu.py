@@ -425,6 +425,7 @@ def test_xstream_query_projection_inside_the_expansion_equals_three_launches(ccx
         prompts = [[rules.sot], [rules.sot_prev, 1000, 2000, rules.sot], [rules.sot], [rules.sot_prev, 77, 88, 99, rules.sot]] * 10
         orc = _oracle(dims, sd)
         monkeypatch.setenv("CCX_CROSS_X_MIN_ROWS", "1")        # 40 sequences would take the K / V path by default
+        monkeypatch.setenv("CCX_DEC_LNFREE", "0")              # round 3's chain (the default chain has its own query kernel, dec_xq_lnfree_kernel)
         for prefill in ("1", "0"):
             monkeypatch.setenv("CCX_PREFILL", prefill)
             monkeypatch.setenv("CCX_XS_FUSE_Q", "1")
@@ -592,13 +593,15 @@ def test_long_prompts_are_prefilled_in_passes_of_16_positions(ccx_ctx, monkeypat
 
 
 def test_layernorm_free_chain_experiment_matches_the_default_chain(ccx_ctx, monkeypatch):
-    """CCX_DEC_LNFREE (experimental, off by default: measured 2 - 5 % slower, profiles/r04_ab_decode_lnfree_chain.txt): the decode chain of
-    the X-stream path without stand-alone resolve / LayerNorm launches -- producers add their product to the residual stream in
-    place and leave bf16 rows + per-tile statistics, consumers apply the LayerNorm algebraically in their epilogue (csrc/decoder.hip
-    DEPI_RESOLVE / ACT_BF16_LN, cross_x.hip dec_xq_lnfree_kernel).  Same tokens as the default chain, log-probabilities to rounding,
-    every token accepted by the oracle, and a sequence's numbers independent of its batch (4 alone = 40 in lanes, bit for bit)."""
+    """CCX_DEC_LNFREE: producers of the residual stream that add their product in place and leave bf16 rows + per-tile statistics,
+    consumers that apply the LayerNorm algebraically in their epilogue (csrc/decoder.hip DEPI_RESOLVE / ACT_BF16_LN, cross_x.hip
+    dec_xq_lnfree_kernel).  Mode 3 (self-attention out + cross-attention query only) is the DEFAULT chain of the X-stream path; 0 is
+    round 3's chain; 1 / 2 (the whole chain without stand-alone LayerNorm launches: measured 2 - 5 % slower,
+    profiles/r04_ab_decode_lnfree_chain.txt), 4 and 5 are experiments.  All of them: the same tokens as round 3's chain,
+    log-probabilities to rounding, every token accepted by the oracle, and a sequence's numbers independent of its batch (4 alone =
+    40 in lanes, bit for bit)."""
     from clearconverse_amd.whisper import WhisperModel
-    monkeypatch.setenv("CCX_DEC_LNFREE", "0")              # the folded weights are built when the instance is created
+    monkeypatch.setenv("CCX_DEC_LNFREE", "0")              # the experiments' folded weights are built when the instance is created
     dims = WhisperDims.mini(n_layer=2, n_state=128)
     sd = synthetic_whisper_state_dict(dims, seed=3)
     m = WhisperModel(dims, sd, max_batch=40, ctx=ccx_ctx)
@@ -611,7 +614,7 @@ def test_layernorm_free_chain_experiment_matches_the_default_chain(ccx_ctx, monk
         m.log_mel(dev, n); xa = m.encode(4, return_xa=True).cpu()
         base = m.decode_greedy(prompts, sample_len=40)
         orc = _oracle(dims, sd)
-        for mode in ("1", "2"):
+        for mode in ("3", "1", "2", "4", "5"):
             monkeypatch.setenv("CCX_DEC_LNFREE", mode)
             m.log_mel(dev, n); m.encode(4)
             small = m.decode_greedy(prompts, sample_len=40)

@@ -11,8 +11,11 @@ from clearconverse_amd.whisper import WhisperModel
 B, steps = int(sys.argv[1]), int(sys.argv[2])
 configs = sys.argv[3:] or ["-"]
 dims = WhisperDims.small_en()
-os.environ.setdefault("CCX_DEC_LNFREE", "0")      # build the folded weights of the LayerNorm-free chain (off until a configuration asks for it)
+had = os.environ.get("CCX_DEC_LNFREE")
+os.environ.setdefault("CCX_DEC_LNFREE", "3")      # present at creation: the instance also builds the folded weights of the chain experiments
 m = WhisperModel(dims, synthetic_whisper_state_dict(dims, seed=0), max_batch=B)
+if had is None:
+    del os.environ["CCX_DEC_LNFREE"]              # "-" then means the library's default
 rules = DecodeRules()
 clips = [synthetic_clip(i, 30.0) for i in range(8)]
 dev = torch.from_numpy(np.stack(clips)).cuda().repeat(B // 8, 1).contiguous()
