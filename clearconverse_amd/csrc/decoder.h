@@ -19,7 +19,6 @@ struct DecLinearParams {
   const float* pend; int pend_n; long pend_stride;  // pending split-K partials [pend_n][M][K] folded into x
   float* x_out;                   // ACT_LN: if non-null, block (0,*,0) writes x + sum(pend) here (must differ from x)
   const float* ln_g; const float* ln_b; float eps;
-  int ln_nt;                      // ACT_LN with more than 16 rows: 16-column tiles per block (4 / 6 / 8 / 12; see ccx_launch_dec_linear)
   const bf16_t* act; long lda;    // ACT_BF16: [M][K]
   const float* part_o; const float* part_ml; int nsplit;  // ACT_COMBINE: [M][H][nsplit][64], [M][H][nsplit][2]
   // ACT_BF16_LN: statistics of the input rows [M][K / 16] (sum, sum of squares per 16-column tile), s [N]; `bias` holds c [N]

@@ -669,24 +669,6 @@ int ccx_launch_dec_linear(ccx_ctx* ctx, int act, int epi, const DecLinearParams&
     if (epi == DEPI_SELF_QKV) return launch_dec_linear_mt<2, ACT_BF16, DEPI_SELF_QKV>(ctx, p, 1, stream);
     if (epi == DEPI_BF16_GELU) return launch_dec_linear_mt<2, ACT_BF16, DEPI_BF16_GELU>(ctx, p, 1, stream);
   }
-  // More than 16 rows with the LayerNorm INSIDE the linear (ACT_LN; whisper.hip chooses it over resolve_ln + ACT_BF16 with
-  // CCX_DEC_LN_FUSE_NT=n): 16-row panels (grid.y) x 16 n columns per block -- every column block of a panel redoes the resolve +
-  // LayerNorm of its 16 rows (N / (16 n) times per panel), so n is large; per output the arithmetic is that of the <= 16-row
-  // instantiation (the same 4 waves x 6 k-steps, the same reduction order), operation for operation.
-  if (act == ACT_LN && p.M > 16 && p.K <= 768) {
-    const int nt = p.ln_nt;
-#define CCX_LNF(NT_)                                                                                                          \
-    do {                                                                                                                        \
-      if (epi == DEPI_SELF_QKV) return launch_dec_linear_inst<1, NT_, 6, ACT_LN, DEPI_SELF_QKV>(ctx, p, 1, stream);             \
-      if (epi == DEPI_F32) return launch_dec_linear_inst<1, NT_, 6, ACT_LN, DEPI_F32>(ctx, p, 1, stream);                       \
-      if (epi == DEPI_BF16_GELU) return launch_dec_linear_inst<1, NT_, 6, ACT_LN, DEPI_BF16_GELU>(ctx, p, 1, stream);           \
-    } while (0)
-    if (nt == 4) CCX_LNF(4);
-    else if (nt == 6) CCX_LNF(6);
-    else if (nt == 12) CCX_LNF(12);
-    else CCX_LNF(8);
-#undef CCX_LNF
-  }
   if (act == ACT_LN && epi == DEPI_SELF_QKV) return launch_dec_linear_mt<1, ACT_LN, DEPI_SELF_QKV>(ctx, p, 1, stream);
   if (act == ACT_LN && epi == DEPI_F32) return launch_dec_linear_mt<1, ACT_LN, DEPI_F32>(ctx, p, 1, stream);
   if (act == ACT_LN && epi == DEPI_BF16_GELU) return launch_dec_linear_mt<1, ACT_LN, DEPI_BF16_GELU>(ctx, p, 1, stream);

@@ -147,7 +147,6 @@ struct ccx_whisper {
   // that takes the K/V path (kv_ready = sequences valid since the last encode).
   static constexpr int kKvSeqs = 80;         // sequences the K/V caches of an X-stream instance hold (4.5 GB at small.en)
   bool xs_on = false, xs_active = false, xs_fuse_q = true;
-  int ln_fuse_nt = 0;                        // CCX_DEC_LN_FUSE_NT, read per decode (see dec_step)
   int last_cross_path = -1;                  // ccx_whisper_last_cross_path: 0 kv16, 1 kv_stream, 2 xa_stream
   int kv_cap = 0, kv_ready = 0;
   bf16_t *xq = nullptr, *pf_xq = nullptr;    // expanded queries [rows][H][D] (step rows, prefill rows)
@@ -1036,11 +1035,7 @@ int dec_step(ccx_whisper* w, int b0, int B, float* logits, long ld, bool select,
     if (extra) lp = *extra; else memset(&lp, 0, sizeof(lp));
     lp.M = B; lp.N = N; lp.K = D; lp.W = W; lp.ldw = D; lp.bias = bias; lp.out = out; lp.ldo = ldo;
     int rc;
-    // CCX_DEC_LN_FUSE_NT=n (4 / 6 / 8 / 12; 0 = off): more than 16 rows also normalise INSIDE the linear, 16-row panels x 16 n columns
-    // per block (decoder.hip) -- one launch instead of two on the chain between two cross attentions
-    const int ln_fuse_nt = w->ln_fuse_nt;
-    lp.ln_nt = ln_fuse_nt;
-    if (B > 16 && !(ln_fuse_nt > 0 && D <= 768)) {
+    if (B > 16) {
       // many sequences: normalise ONCE in a stand-alone kernel instead of redundantly in every weight-panel block
       rc = ccx_launch_dec_resolve_ln(ctx, cur, pend, pend_n, pstride, g, bta, dxn, pend_n > 0 ? other : nullptr, B, D, 1e-5f, stream);
       if (rc) return rc;
@@ -1496,7 +1491,6 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
     static const int lean = [] { const char* e = getenv("CCX_CROSS_STREAM"); return e ? atoi(e) : 1; }();
     w->cross_stream = lean;
     { const char* e = getenv("CCX_FUSE_CROSS_Q"); w->fuse_cross_q = e ? (atoi(e) != 0) : 1; }      // read per decode: tests flip it
-    { const char* e = getenv("CCX_DEC_LN_FUSE_NT"); w->ln_fuse_nt = e ? atoi(e) : 0; }
     // default 3: the self-attention output projection resolves the residual in place and the cross-attention query applies its
     // LayerNorm algebraically (no twelve-fold resolve + LayerNorm inside the expansion kernel; -1.0 ... -1.2 % per decode step);
     // 0: round 3's chain; 1 / 2 / 4 / 5: the experiments of DESIGN.md section 2 (need the instance created with CCX_DEC_LNFREE set)
@@ -1552,7 +1546,7 @@ int ccx_whisper_decode(ccx_whisper* w, const int32_t* prompt_ids, const int32_t*
       // graphs are specific to (lane rows, sample_len, max_prompt)
       // ... and to everything else dec_step bakes into kernel parameters: the cross-attention LDS cap and split count
       const int ns_key = cross_split(lanes[i].B, w->d.n_text_head, w->cross_lds_pad > 0, w->cross_stream != 0);
-      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8) | ((w->xs_fuse_q ? 1 : 0) << 9) | (w->ln_fuse_nt << 10) | (w->lnfree_mode << 16), i};
+      const std::array<int, 9> key = {lanes[i].b0, lanes[i].B, sample_len, max_prompt, w->sampling ? 1 : 0, ns_key, w->cross_lds_pad, w->cross_stream | (w->fuse_cross_q << 4) | ((w->xs_active ? 1 : 0) << 8) | ((w->xs_fuse_q ? 1 : 0) << 9) | (w->lnfree_mode << 16), i};
       auto it = w->graphs.find(key);
       if (it != w->graphs.end()) { lanes[i].exec = it->second; continue; }
       hipGraph_t graph = nullptr;

@@ -219,6 +219,26 @@ class EnhancedAudioProcessor:
             log.error("Error in embedding extraction: %s", e)
             return None
 
+    def _embed_many(self, crops: Sequence[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+        """`_extract_embedding` for several crops.  A model with `embed_batch` (clearconverse_amd.speaker.XVectorEmbedder) embeds the
+        eligible ones in one launch group and keeps the results on the device; any other model -- the reference's duck-typed object,
+        the scripted stubs -- is called crop by crop in order, exactly as the reference's loop does (back/api.py:974-977)."""
+        em = self.embedding_model
+        if not (hasattr(em, "embed_batch") and getattr(self, "batch_embeddings", True) and os.environ.get("CCX_BATCH_EMBEDDINGS", "1") != "0"):
+            return [self._extract_embedding(c) for c in crops]
+        ok = [i for i, c in enumerate(crops) if c.shape[-1] >= self.config.target_sample_rate / 2]
+        out: List[Optional[torch.Tensor]] = [None] * len(crops)
+        if not ok:
+            return out
+        try:
+            embs = em.embed_batch([crops[i].detach().reshape(-1) for i in ok])
+            for j, i in enumerate(ok):
+                out[i] = embs[j].to(self.device)
+        except Exception as e:  # noqa: BLE001 -- attribute the failure crop by crop, as the serial path would
+            log.error("batched embedding failed (%s): embedding the %d crops one by one", e, len(ok))
+            return [self._extract_embedding(c) for c in crops]
+        return out
+
     @staticmethod
     def _calculate_embedding_similarity(a: torch.Tensor, b: torch.Tensor) -> float:
         return torch.nn.functional.cosine_similarity(a, b, dim=0).item()
@@ -271,10 +291,16 @@ class EnhancedAudioProcessor:
         if span < 2.0:
             hop = min(hop, span / 4)
         votes: List[Tuple[float, float, str, float]] = []
+        # the windows' positions first (the loop's own float arithmetic), so that their embeddings can be computed as ONE batch by a
+        # model that offers embed_batch: an embedding does not depend on its batch mates, and the loop below reads labels only
+        starts: List[float] = []
         pos = seg_start
-        prev: Optional[str] = None
         while pos + win <= seg_end:
-            emb = self._extract_embedding(self._extract_segment(audio_segment, pos - seg_start, pos - seg_start + win))
+            starts.append(pos)
+            pos += hop
+        embs = self._embed_many([self._extract_segment(audio_segment, p0 - seg_start, p0 - seg_start + win) for p0 in starts])
+        prev: Optional[str] = None
+        for pos, emb in zip(starts, embs):
             if emb is None:
                 who, conf = (prev if prev else "UNKNOWN"), 0.0
             else:
@@ -288,7 +314,6 @@ class EnhancedAudioProcessor:
                             who, conf = prev, second_conf
                 prev = who
             votes.append((pos, pos + win, who, conf))
-            pos += hop
         if not votes:
             return [(seg_start, seg_end, "UNKNOWN")]
         floor = min(0.3, span / 10)

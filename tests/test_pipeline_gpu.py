@@ -109,6 +109,7 @@ def test_two_pass_schedule_batched_whisper_calls_equal_the_serial_order(scripted
                                        model_loader=lambda cfg, dev: scripted_models)
             p._initialize_models()
             p.batch_whisper_calls = batched
+            p.batch_embeddings = batched              # the sliding-window embeddings of an overlap segment as one batch / one by one
             calls = []
             wm = scripted_models["whisper_model"]
             orig = wm.transcribe_batch
