@@ -193,3 +193,30 @@ def test_two_pass_schedule_overlap_failure_becomes_a_marker_segment():
     assert len(marked) >= 1 and all(s_.confidence == 0.0 and s_.is_overlap for s_ in marked)
     assert len(res["segments"]) == len(ref["segments"])
     assert sum(s_.transcription != "[Processing error]" for s_ in res["segments"]) >= 1
+
+
+def test_sliding_window_embeddings_batched_equal_the_loop():
+    """`_resegment_overlap` embeds its windows through `_embed_many`: one `embed_batch` call per overlap segment for a model that offers
+    it, the reference's loop (back/api.py:974-977) otherwise.  Same regions, same labels, same separator / Whisper calls either way."""
+    class BatchEmbedding(StubEmbedding):
+        def __init__(self):
+            super().__init__()
+            self.batches = []
+
+        def embed_batch(self, crops):
+            self.batches.append(len(crops))
+            return torch.stack([torch.from_numpy(self({"waveform": c.reshape(1, -1), "sample_rate": 16000})) for c in crops])
+    for name in ("two_speakers_one_overlap_30s", "custom_thresholds", "short_overlap_segment"):
+        sc = Scenario.from_json(PROCESS["scenarios"][name]["scenario"])
+        outs = []
+        for batched in (False, True):
+            p, diar_calls = _build(sc)
+            p.embedding_model = BatchEmbedding()
+            p.batch_embeddings = batched
+            res = p.process_file("clip.wav")
+            outs.append((result_to_json(res, p.whisper_model.calls, p.separator.calls, diar_calls), p.embedding_model.batches))
+        (a, ba), (b, bb) = outs
+        _close(json.loads(json.dumps(b)), json.loads(json.dumps(a)), name)
+        exp = dict(PROCESS["scenarios"][name]["expected"]); exp.pop("transcript", None)
+        _close(json.loads(json.dumps(b)), exp, name)                       # ... and both equal the reference-generated fixture
+        assert ba == [] and len(bb) >= 1 and max(bb) > 1, (name, bb)

@@ -8,7 +8,7 @@ the loop strides by 256, so only decodes past position 64 use waves 1-3 and only
 positional embedding, ApplyTimestampRules over long histories and the n_text_ctx edge are exercised by nothing shorter either.
 
 Every GPU token is walked through the oracle's KV-cached decoder (the arithmetic of `decoder_logits`, one token per call) under
-teacher forcing: it must be an eps-argmax of the oracle's filtered logits (eps 0.02 at mini dims, 0.03 at full small.en size: 2.5 x
+teacher forcing: it must be an eps-argmax of the oracle's filtered logits (eps 0.02 at mini dims, 0.0275 at full small.en size: 2.5 x
 the worst shortfall measured, 7.9e-3 / 1.1e-2; the short-decode tests use 0.05 / 0.08), equal to the argmax where the oracle's margin
 exceeds 2 eps, and the summed log-probability and the no-speech probability must agree.  Paths: the split-KV kernels of <= 16 sequences ("kv16"), the lean K / V stream of 17 - 80
 sequences ("kv_stream", the default of that range) and the cross attention against the encoder output ("xa_stream", > 80
@@ -127,7 +127,7 @@ def test_mini_decodes_of_224_tokens_and_the_448_position_edge(ccx_ctx, monkeypat
                     walk_cached(orc, xa[i:i + 1], prompts[i], stepwise[i], 224, 0.02, f"whisper mini long decode, stepwise prompt [{path}]")
                 else:
                     within("whisper mini long decode [kv_stream]: |sum_logprob prefilled - stepwise prompt| / max(1, |.|)",
-                           abs(stepwise[i]["sum_logprob"] - res[i]["sum_logprob"]) / max(1.0, abs(res[i]["sum_logprob"])), 1e-4, i)
+                           abs(stepwise[i]["sum_logprob"] - res[i]["sum_logprob"]) / max(1.0, abs(res[i]["sum_logprob"])), 3.5e-5, i)
             else:
                 assert stepwise[i]["tokens"] == res[i]["tokens"] and stepwise[i]["sum_logprob"] == res[i]["sum_logprob"], i
         # the edge: one more position is refused, loudly
@@ -161,7 +161,7 @@ def test_full_size_decodes_of_224_tokens_against_the_oracle(ccx_ctx, monkeypatch
         decisive = 0
         for i in range(2):
             assert len(res[i]["tokens"]) >= 200
-            decisive += walk_cached(orc, xa[i:i + 1], prompts[i], res[i], 224, 0.03, f"whisper small.en FULL size long decode [{path}]")[1]
+            decisive += walk_cached(orc, xa[i:i + 1], prompts[i], res[i], 224, 0.0275, f"whisper small.en FULL size long decode [{path}]")[1]
         assert decisive >= 20, decisive
     finally:
         m.close()
@@ -194,13 +194,13 @@ def test_full_size_default_path_of_24_sequences_against_the_oracle_and_the_xa_st
         orc = R.WhisperRef(R.Dims(**dims.__dict__), sd)
         tipped = 0
         for i in range(24):
-            walk_cached(orc, xa[i:i + 1], prompts[i], res[i], S, 0.03, "whisper small.en FULL size, 24 sequences [kv_stream]")
+            walk_cached(orc, xa[i:i + 1], prompts[i], res[i], S, 0.0275, "whisper small.en FULL size, 24 sequences [kv_stream]")
             if res[i]["tokens"] == xs[i]["tokens"]:
                 within("whisper small.en FULL size: |sum_logprob kv_stream - xa_stream| / max(1, |.|)",
-                       abs(res[i]["sum_logprob"] - xs[i]["sum_logprob"]) / max(1.0, abs(xs[i]["sum_logprob"])), 2e-3, i)
+                       abs(res[i]["sum_logprob"] - xs[i]["sum_logprob"]) / max(1.0, abs(xs[i]["sum_logprob"])), 8e-4, i)
             else:
                 tipped += 1
-                walk_cached(orc, xa[i:i + 1], prompts[i], xs[i], S, 0.03, "whisper small.en FULL size, 24 sequences [xa_stream]")
+                walk_cached(orc, xa[i:i + 1], prompts[i], xs[i], S, 0.0275, "whisper small.en FULL size, 24 sequences [xa_stream]")
         assert tipped <= 6, tipped
     finally:
         m.close()
