@@ -259,7 +259,18 @@ class BatchPipeline:
         torch.cuda.current_stream(dev).synchronize()      # the inputs were produced on the caller's stream
         grp = min(self.group, whs[0].max_batch)
 
-        trace = getattr(self, "trace", None)       # optional list: (what, batch unit, t_start, t_end) host times of both threads
+        # optional list: (what, batch unit, t_start, t_end) -- decodes in host time of the worker thread, front ends and encodes as
+        # stream events (resolved to the same clock after the run: the front thread is never synchronised for the trace)
+        trace = getattr(self, "trace", None)
+        ev_trace = []
+        if trace is not None:
+            self._front_stream.synchronize()
+            ev_base = torch.cuda.Event(enable_timing=True); ev_base.record(self._front_stream); ev_base.synchronize()
+            t_base = time.perf_counter()
+
+        def stamp():
+            e = torch.cuda.Event(enable_timing=True); e.record(self._front_stream)
+            return e
 
         def decode_task(k: int, prompts, ready: torch.cuda.Event, u: int):
             with torch.cuda.stream(self._dec_streams[k]):
@@ -278,10 +289,12 @@ class BatchPipeline:
         with ThreadPoolExecutor(max_workers=1) as ex, torch.cuda.stream(self._front_stream):
             held = []                           # front states waiting for the rest of their span
             for ai, audio in enumerate(audios):
-                tf0 = time.perf_counter()
+                e0 = stamp() if trace is not None else None
+                th0 = time.perf_counter()
                 held.append(self._front(audio, False, debug))
                 if trace is not None:
-                    self._front_stream.synchronize(); trace.append(("front", unit, tf0, time.perf_counter()))
+                    ev_trace.append(("front", unit, e0, stamp()))
+                    trace.append(("front-host", unit, th0, time.perf_counter()))
                 if len(held) < max(1, span) and ai + 1 < len(audios):
                     continue
                 # one Whisper unit for the windows of every held batch
@@ -294,7 +307,7 @@ class BatchPipeline:
                     if slot_busy[k] is not None:
                         slot_busy[k].result()                      # the instance's previous windows are decoded
                     w = whs[k]
-                    te0 = time.perf_counter()
+                    e0 = stamp() if trace is not None else None
                     part = crops[i0:i0 + grp]
                     buf, n = self._pad_batch(part)
                     w.log_mel(buf, n)
@@ -302,7 +315,7 @@ class BatchPipeline:
                     ready = torch.cuda.Event()
                     ready.record(self._front_stream)
                     if trace is not None:
-                        ready.synchronize(); trace.append(("encode", unit, te0, time.perf_counter()))
+                        ev_trace.append(("encode", unit, e0, stamp()))
                     tok = w.tokenizer
                     pr = [w.initial_tokens(tok.encode(" " + p.strip()) if p else []) for p in prompts[i0:i0 + len(part)]]
                     pids += pr
@@ -318,6 +331,8 @@ class BatchPipeline:
             for u in pending:
                 out += self._finish_unit(*u, debug)
             self._front_stream.synchronize()
+        for what, u, e0, e1 in ev_trace:
+            trace.append((what, u, t_base + ev_base.elapsed_time(e0) * 1e-3, t_base + ev_base.elapsed_time(e1) * 1e-3))
         return out
 
     def _finish_unit(self, held, bounds, futs, pids, debug) -> List[Dict[str, object]]:
