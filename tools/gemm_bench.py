@@ -1,5 +1,6 @@
 """Stand-alone timing of ccx_gemm_bf16 on the Whisper encoder's shapes (192 windows: M = 288 000), random operands.
-CCX_GEMM_PHASED=0 selects the two-stage 256 x 256 kernel for an A/B run in a second process."""
+CCX_GEMM_PHASED=0 selects the two-stage 256 x 256 kernel for an A/B run in a second process; GEMM_ITERS / GEMM_ONLY=<qkv|out|fc1|fc2>
+for long single-shape runs (tools/power_sampler.py)."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +11,10 @@ lib = ctx.lib
 M = int(os.environ.get("GEMM_M", "288000"))
 shapes = [("qkv", 0, 2304, 768), ("out", 2, 768, 768), ("fc1", 1, 3072, 768), ("fc2", 2, 768, 3072)]
 st = int(torch.cuda.current_stream().cuda_stream)
+only = os.environ.get("GEMM_ONLY")
 for name, epi, N, K in shapes:
+    if only and name != only:
+        continue
     g = torch.Generator().manual_seed(N)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).cuda()
@@ -26,7 +30,7 @@ for name, epi, N, K in shapes:
         run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
+    n = int(os.environ.get("GEMM_ITERS", "20"))
     e0.record()
     for _ in range(n):
         run()
