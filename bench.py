@@ -114,6 +114,64 @@ def cpu_baseline_pipeline(models_sd, clip, rules, threads):
     return 30.0 / t_clip, sample
 
 
+class PowerProbe:
+    """Socket power and shader clock of rank 0's card over the timed region: hwmon power1_input / freq1_input read every 50 ms by a
+    thread (no HIP, no subprocess once the GPU is initialised: the card is looked up BEFORE, with `rocm-smi --showbus` -- the host's other
+    cards belong to other boxes).  Reported as `power` in the JSON line; null when the files are not there.  tools/power_sampler.py is
+    the stand-alone form."""
+
+    def __init__(self):
+        import glob, re, subprocess
+        self.h = None
+        try:
+            out = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=30).stdout
+            m = re.search(r"GPU\[0\].*?([0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F])", out)
+            bdf = m.group(1).lower() if m else None
+            for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if bdf and os.path.basename(os.path.realpath(os.path.join(h, "device"))).lower() == bdf:
+                    self.h = h
+        except Exception:
+            self.h = None
+        self.samples, self._stop, self._thr = [], False, None
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return int(f.read().strip())
+
+    def start(self):
+        if self.h is None:
+            return
+        import threading
+
+        def loop():
+            while not self._stop:
+                try:
+                    self.samples.append((self._read(os.path.join(self.h, "power1_input")) * 1e-6, self._read(os.path.join(self.h, "freq1_input")) * 1e-6))
+                except (OSError, ValueError):
+                    pass
+                time.sleep(0.05)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr is None:
+            return None
+        self._stop = True
+        self._thr.join(timeout=2.0)
+        if not self.samples:
+            return None
+        pw = sorted(x[0] for x in self.samples)
+        ck = sorted(x[1] for x in self.samples)
+        try:
+            cap = self._read(os.path.join(self.h, "power1_cap")) * 1e-6
+        except (OSError, ValueError):
+            cap = None
+        return {"mean_w": round(sum(pw) / len(pw), 1), "median_w": round(pw[len(pw) // 2], 1), "p95_w": round(pw[int(len(pw) * 0.95)], 1),
+                "cap_w": cap, "sclk_mhz_mean": round(sum(ck) / len(ck)), "sclk_mhz_min": round(ck[0]), "samples": len(pw),
+                "source": "hwmon power1_input / freq1_input of rank 0's card, every 50 ms over the timed region"}
+
+
 def spawn_ranks(n: int) -> int:
     """One process per GPU on this node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same args>`
     on 127.0.0.1 with a free port (the container hostname may not resolve).  Returns the launcher's exit code."""
@@ -263,6 +321,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} or without a launcher")
+    probe = PowerProbe() if (rank == 0 and local_rank == 0) else None      # looks its card up before anything touches the GPU
     if os.environ.get("CCX_BENCH_SHARE_GPU"):
         local_rank = 0      # rehearsal of the N > 1 code path on a one-GPU box (with CCX_BENCH_BACKEND=gloo): all ranks on cuda:0
     torch.cuda.set_device(local_rank)
@@ -361,6 +420,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    if probe is not None:
+        probe.start()
     t0 = time.perf_counter()
     n_tokens = n_calls = 0
     res = None
@@ -372,6 +433,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    power = probe.stop() if probe is not None else None
     seq_ms = span1_ms = None
     if pipelined and args.decode_span > 1 and not args.no_comparisons:
         # the same pipeline with one decode group per batch, for comparison (untimed for `value`)
@@ -692,6 +754,7 @@ def main():
             "ccx_env": dict(ccx_env, **({} if "CCX_PROF_SHAPES" in ccx_env else {"CCX_PROF_SHAPES": "1 (set by bench.py: labels of the profiled step only)"})),
             "model_load_ms": round(load_ms, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 1),
+            "power": power,
             "hbm_used_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
         }
         print(json.dumps(out), flush=True)
