@@ -4,6 +4,7 @@
 // row, 24 x 16-byte loads per lane in flight (4 tiles of 16 keys), cacheable loads, values xor-ed into a sink.
 // build: hipcc -w --offload-arch=gfx950 -O3 tools/microbench_linehalves.hip -o /tmp/linehalves && /tmp/linehalves
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(4))) unsigned u4;
 
@@ -63,6 +64,33 @@ int main() {
       const double bytes = (double)rows * S * 768 * 2;
       printf("rows %3d  %s  %7.1f us  %5.2f TB/s  %5.1f GB/s per busy CU\n", rows, full ? "full lines (8 rows x 128 B)" : "half lines (16 rows x 64 B)",
              best * 1e3, bytes / (best * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e9 / (rows < 256 ? rows : 256));
+    }
+  }
+  // the same kernel on a stream restricted to N CUs (hipExtStreamCreateWithCUMask, the first N mask bits = N / 8 CUs of every XCD):
+  // how many CUs does it take to pull the whole HBM rate, with half and with full lines, at 1 - 4 blocks per CU?
+  for (int ncu : {64, 96, 128, 160}) {
+    unsigned mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st;
+    if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) { printf("hipExtStreamCreateWithCUMask failed\n"); return 1; }
+    for (int per : {1, 2, 3, 4}) {
+      const int rows = ncu * per;
+      if (rows > rows_max) continue;
+      for (int full = 0; full < 2; full++) {
+        float best = 1e9;
+        for (int it = 0; it < 5; it++) {
+          hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+          hipEventRecord(a, st);
+          if (full) hipLaunchKernelGGL(stream_kernel<1>, dim3(rows), dim3(256), 0, st, X, sink, S);
+          else hipLaunchKernelGGL(stream_kernel<0>, dim3(rows), dim3(256), 0, st, X, sink, S);
+          hipEventRecord(b, st); hipEventSynchronize(b);
+          float ms; hipEventElapsedTime(&ms, a, b);
+          if (ms < best) best = ms;
+        }
+        const double bytes = (double)rows * S * 768 * 2;
+        printf("%3d CUs x %d blocks  %s  %7.1f us  %5.2f TB/s  %5.1f GB/s per CU\n", ncu, per, full ? "full lines" : "half lines", best * 1e3,
+               bytes / (best * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e9 / ncu);
+      }
     }
   }
   return 0;
